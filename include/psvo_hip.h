@@ -1,0 +1,148 @@
+/*
+ * psvo_hip.h -- C ABI of the MI355X-native PSVO hot path (libpsvo_hip.so).
+ *
+ * The reference (amoretti86/PSVO) has no FFI/plugin registry: the hot path sits behind a
+ * Python object protocol (`Obj(model, FLAGS).get_log_ZSMC(obs, hidden)`, reference
+ * src/trainer.py:108, src/runner.py:70-79).  This header is the boundary a maintainer would
+ * bind from that protocol; each entry point names the reference code it replaces.
+ * INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless it says "host"; float = fp32, indices int32;
+ *   - the caller allocates every input, output and workspace buffer; the library never
+ *     allocates device memory and keeps no pointer after a call returns;
+ *   - every entry point is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 = ok, <0 = psvo_status error (see psvo_status_string);
+ *   - HBM layout is particle-minor SoA so that a wavefront's lanes (particles) are contiguous:
+ *         particles  X[t][b][d][n]      -> (T, B, Dx, N)
+ *         weights    logW[t][b][n]      -> (T, B, N)
+ *         per-seq    lse[t][b]          -> (T, B)
+ *         features   mu2[t][b][d]       -> (T, B, Dx),  obs[t][b][e] -> (T, B, Dy)
+ *         bsim noise eps_b[t][b][d][n][m] -> (T, B, Dx, N, M)
+ *     (the reference's own internal layout is (T, N, B, D), src/SMC/SVO.py:176-178; the
+ *     host mirror permutes to the reference's (B, T, N, Dx) at the Python boundary).
+ *   - per-particle MLPs have ONE hidden layer of width H (reference default `*_layers=[32]`,
+ *     src/runner_flag.py:53-57); kernels are instantiated for Dx in {1..4}, Dy in {1,2,3},
+ *     H in {8,16,32,64}.  Anything else returns PSVO_ERR_UNSUPPORTED (never a silent fallback).
+ */
+#ifndef PSVO_HIP_H
+#define PSVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSVO_ABI_VERSION 1
+
+typedef enum {
+    PSVO_OK = 0,
+    PSVO_ERR_INVALID = -1,      /* null pointer / non-positive size / inconsistent desc       */
+    PSVO_ERR_UNSUPPORTED = -2,  /* (Dx, Dy, H, M, N) outside the instantiated kernel set      */
+    PSVO_ERR_HIP = -3           /* a HIP runtime call failed (launch error)                   */
+} psvo_status;
+
+/* Problem descriptor.  Mirrors the reference FLAGS that shape the path
+ * (src/runner_flag.py:22-28,88-113; read at src/SMC/SVO.py:7-29, src/SMC/PSVO.py:9-19). */
+typedef struct {
+    int32_t B;          /* sequences in this call (FLAGS.batch_size, local shard)              */
+    int32_t T;          /* time steps (FLAGS.time)                                             */
+    int32_t N;          /* FLAGS.n_particles                                                   */
+    int32_t M;          /* FLAGS.n_particles_for_BSim_proposal (bsim only)                     */
+    int32_t Dx;         /* FLAGS.Dx                                                            */
+    int32_t Dy;         /* FLAGS.Dy                                                            */
+    int32_t H;          /* hidden width of q1 / f / g / q1_inv MLPs                            */
+    int32_t resample;   /* 1: multinomial resampling every step (SVO/AESMC/PSVO); 0: IWAE      */
+    int32_t two_q;      /* FLAGS.use_2_q                                                       */
+    int32_t bootstrap;  /* FLAGS.use_bootstrap (f shares q1's MLP and sigma)                   */
+} psvo_desc;
+
+/* One-hidden-layer MLP, keras Dense layout (reference src/transformation/MLP.py:27-46):
+ * W1 (Din, H) row-major, b1 (H), W2 (H, Dout) row-major, b2 (Dout). */
+typedef struct {
+    const float* W1;
+    const float* b1;
+    const float* W2;
+    const float* b2;
+} psvo_mlp;
+
+int psvo_abi_version(void);
+const char* psvo_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * Forward particle filter.  Replaces SVO.SMC (reference src/SMC/SVO.py:60-180) including
+ * sample_from_2_dist (:182-232, diagonal branch), resample_X / get_resample_idx (:243-300)
+ * and the per-step reduce_logsumexp of compute_log_ZSMC (:302-311).
+ *
+ * One persistent workgroup per sequence loops over t in-kernel.
+ *
+ *  q1, f, g       per-particle MLPs; when desc->bootstrap != 0, `f` is ignored (f == q1).
+ *  sig_q1/sig_q2/sig_f (Dx), sig_g (Dy)  already-clipped scales max(softplus(raw), min)
+ *                 (src/distribution/mvn.py:80-90); sig_q2 ignored when !two_q;
+ *                 sig_f ignored when bootstrap.
+ *  mu2  (T,B,Dx)  hoisted MLP_q2(e_t[b]) (proposal term that does not depend on particles);
+ *                 ignored when !two_q.
+ *  m0   (B,Dx), sig0 (Dx)   t=0 proposal term: MLP_q0(X0 feature), sigma_q0 (SVO.py:80-88).
+ *  fm0  (B,Dx), fsig0 (Dx)  t=0 transition term: equal to (m0, sig0) when bootstrap&&two_q,
+ *                 else (MLP_f(X0 feature), sigma_f) (SVO.py:91-92).
+ *  obs  (T,B,Dy)
+ *  eps  (T,B,Dx,N) standard-normal draws (injected; the reference draws them with mvn.sample)
+ *  u    (T,B,N)   uniforms in [0,1) for the multinomial draw; used when idx_in == NULL
+ *  idx_in (T,B,N) int32 teacher-forced ancestor indices or NULL
+ *
+ *  outputs: X (T,B,Dx,N) pre-resampling particles (Xs_ta), Xanc (T,B,Dx,N) resampled particles
+ *  (X_ancestors_ta), Fm (T,B,Dx,N) = MLP_f(X_t) (transition means of every forward particle,
+ *  consumed by the backward simulation), logW (T,B,N) (log_Ws_ta), idx_out (T,B,N) ancestors,
+ *  lse (T,B) = logsumexp_n logW[t,b,:].
+ * ------------------------------------------------------------------------------------------- */
+int psvo_filter_forward(const psvo_desc* desc,
+                        const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
+                        const float* sig_q1, const float* sig_q2, const float* sig_f, const float* sig_g,
+                        const float* mu2,
+                        const float* m0, const float* sig0, const float* fm0, const float* fsig0,
+                        const float* obs, const float* eps, const float* u, const int32_t* idx_in,
+                        float* X, float* Xanc, float* Fm, float* logW, int32_t* idx_out, float* lse,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward simulation with proposal.  Replaces PSVO.backward_simulation_w_proposal
+ * (reference src/SMC/PSVO.py:69-203): the (M, N, N, B) transition tile (:128-133) is never
+ * materialised -- forward-particle means are staged in LDS and reduced with an online
+ * log-sum-exp.
+ *
+ *  X, Fm, logW, lse      outputs of psvo_filter_forward (pre-resampling history, PSVO.py:39)
+ *  f, g, q1_inv          per-particle MLPs (f == q1 when bootstrap: pass q1)
+ *  sig_f, sig_g, sig_q1inv, sig_bq2 (Dx / Dy)
+ *  bmu2 (T,B,Dx)         hoisted MLP_BSim_q2(enc_t[b])
+ *  minit (B,Dx), sig_init (Dx)   MLP_BSim_q_init(enc_{T-1}[b]), its sigma (PSVO.py:86-87)
+ *  imean (B,Dx), isig (Dx)       t=0 "filter" term: (MLP_q0(mu_0), sigma_q0) when
+ *                        bootstrap&&two_q else (MLP_f(mu_0), sigma_f) (PSVO.py:169-173)
+ *  obs (T,B,Dy); eps_b (T,B,Dx,N,M) normal draws; u_b (T,B,N) uniforms; sel_in (T,B,N) or NULL
+ *
+ *  outputs: bwX (T,B,Dx,N) (bw_Xs), flp (T,B,N) (f_log_probs), glp (T,B,N) (g_log_probs),
+ *  Omega (T,B,N) (bw_log_Omegas), sel_out (T,B,N) chosen sub-particle, score (B,N) =
+ *  sum_t(flp+glp-Omega), elbo_b (B) = logsumexp_n score - log N (PSVO.compute_log_ZSMC :52-67
+ *  before the batch mean).
+ * ------------------------------------------------------------------------------------------- */
+int psvo_bsim_forward(const psvo_desc* desc,
+                      const float* X, const float* Fm, const float* logW, const float* lse,
+                      const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
+                      const float* sig_f, const float* sig_g, const float* sig_q1inv, const float* sig_bq2,
+                      const float* bmu2, const float* minit, const float* sig_init,
+                      const float* imean, const float* isig,
+                      const float* obs, const float* eps_b, const float* u_b, const int32_t* sel_in,
+                      float* bwX, float* flp, float* glp, float* Omega, int32_t* sel_out,
+                      float* score, void* stream);
+
+/* Per-sequence ELBO reductions (no batch mean: the caller averages, so a batch shard can be
+ * all-reduced).  filter: out[b] = sum_t lse[t,b] (SVO.compute_log_ZSMC, SVO.py:302-311);
+ * bsim: out[b] = logsumexp_n score[b,n] - log N (PSVO.compute_log_ZSMC, PSVO.py:52-67). */
+int psvo_elbo_filter(const psvo_desc* desc, const float* lse, float* out, void* stream);
+int psvo_elbo_bsim(const psvo_desc* desc, const float* score, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSVO_HIP_H */

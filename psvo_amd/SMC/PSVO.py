@@ -1,0 +1,76 @@
+"""PSVO -- mirror of reference src/SMC/PSVO.py:8-216: forward filter, then backward simulation
+with proposal.  The backward simulation (PSVO.py:69-203, the (M, N, N, B) transition tile) is
+ONE persistent HIP kernel (psvo_bsim_forward, psvo_amd/csrc/bsim_fwd.hip)."""
+import torch
+
+from .. import ops
+from .SVO import SVO, _c
+
+
+class PSVO(SVO):
+    def __init__(self, model, FLAGS, name="log_ZSMC"):
+        SVO.__init__(self, model, FLAGS, name="log_ZSMC")
+
+        self.n_particles_for_BSim_proposal = FLAGS.n_particles_for_BSim_proposal
+
+        self.smooth_obs = False
+        self.BSim_use_single_RNN = FLAGS.BSim_use_single_RNN
+
+        self.q1_inv = model.q1_inv_dist
+        self.BSim_q_init = model.Bsim_q_init_dist
+        self.BSim_q2 = model.BSim_q2_dist
+
+    def get_log_ZSMC(self, obs, hidden, noise=None):
+        """PSVO.py:21-50.  Extra `noise` keys: eps_b (T,B,Dx,N,M), u_b (T,B,N) or sel_b (T,B,N) int32."""
+        batch_size, time, _ = obs.shape
+        self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
+
+        log = {}
+        filt = self.SMC(hidden, obs, noise=noise)                      # pre-resampling X and log_Ws
+        bs = self.backward_simulation_w_proposal(filt, obs, noise=noise)
+        log_ZSMC = self.compute_log_ZSMC_bsim(bs["score"])
+        log["Xs"] = bs["bwX"].permute(1, 0, 3, 2)                      # (B, T, N, Dx)
+        log["filter"], log["bsim"] = filt, bs
+        return log_ZSMC, log
+
+    def compute_log_ZSMC_bsim(self, score):
+        """PSVO.py:52-67: mean_b [ logsumexp_n( sum_t(f+g) - sum_t Omega ) - log N ]."""
+        return ops.elbo_bsim(self._desc(self.n_particles_for_BSim_proposal), score).mean()
+
+    def backward_simulation_w_proposal(self, filt, obs, noise=None):
+        model = self.model
+        Dx, T, N, B = self.Dx, self.time, self.n_particles, self.batch_size
+        M = self.n_particles_for_BSim_proposal
+        dev = obs.device
+        noise = noise or {}
+
+        _, preprocessed_obs = self.BS_preprocess_obs(obs)                        # (B, T, 2Dh)
+        bmu2 = self.BSim_q2.mean(preprocessed_obs).transpose(0, 1).contiguous()   # (T, B, Dx)
+        minit = self.BSim_q_init.mean(preprocessed_obs[:, -1])                   # (B, Dx)
+        mu_0 = self.preprocessed_X0                                              # cached by SMC()
+        if not (model.use_bootstrap and model.use_2_q):
+            imean, isig = self.f.mean(mu_0), self.f.get_sigma()                  # PSVO.py:171
+        else:
+            imean, isig = self.q0.mean(mu_0), self.q0.get_sigma()                # PSVO.py:173
+
+        eps_b = noise.get("eps_b")
+        if eps_b is None:
+            eps_b = self._randn(T, B, Dx, N, M, device=dev)
+        u_b, sel_in = noise.get("u_b"), noise.get("sel_b")
+        if u_b is None and sel_in is None:
+            u_b = self._rand(T, B, N, device=dev)
+        obs_TB = obs.transpose(0, 1).contiguous().float()
+
+        with torch.no_grad():
+            bs = ops.bsim_forward(
+                self._desc(M), filt, _c(model.f_tran.hip_params()), _c(model.g_tran.hip_params()),
+                _c(model.q1_inv_tran.hip_params()), _c(self.f.get_sigma()), _c(self.g.get_sigma()),
+                _c(self.q1_inv.get_sigma()), _c(self.BSim_q2.get_sigma()), _c(bmu2), _c(minit),
+                _c(self.BSim_q_init.get_sigma()), _c(imean), _c(isig), obs_TB, eps_b, u_b, sel_in)
+        return bs
+
+    def BS_preprocess_obs(self, obs):
+        """PSVO.py:205-216."""
+        if self.BSim_use_single_RNN:
+            raise NotImplementedError("BSim_use_single_RNN (unidirectional static_rnn) is not built yet")
+        return self.preprocess_obs_w_bRNN(obs)

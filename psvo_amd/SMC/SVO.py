@@ -1,0 +1,164 @@
+"""SVO -- mirror of reference src/SMC/SVO.py:6-409.
+
+The forward particle filter (SVO.SMC, :60-180, with sample_from_2_dist :182-232 and
+resample_X / get_resample_idx :243-300) runs as ONE persistent HIP kernel
+(psvo_filter_forward, psvo_amd/csrc/filter_fwd.hip).  This class only prepares what does not
+depend on the particles -- encoder features and the hoisted q0 / q2 means, B*T rows -- and
+permutes the result to the reference's (batch, time, particles, Dx).
+"""
+import torch
+
+from .. import ops
+
+
+class SVO:
+    def __init__(self, model, FLAGS, name="log_ZSMC"):
+        self.model = model
+
+        # SSM distributions
+        self.q0 = model.q0_dist
+        self.q1 = model.q1_dist
+        self.q2 = model.q2_dist
+        self.f = model.f_dist
+        self.g = model.g_dist
+
+        self.n_particles = FLAGS.n_particles
+        self.q_uses_true_X = FLAGS.q_uses_true_X
+
+        # bidirectional RNN as full sequence observations encoder
+        self.X0_use_separate_RNN = FLAGS.X0_use_separate_RNN
+        self.use_stack_rnn = FLAGS.use_stack_rnn
+
+        self.smooth_obs = True
+        self.resample_particles = True
+
+        self.name = name
+        self.generator = None        # torch.Generator on the compute device; None = global RNG
+
+    # ------------------------------------------------------------------------------------------
+    def get_log_ZSMC(self, obs, hidden, noise=None):
+        """obs (batch, time, Dy), hidden (batch, time, Dx) -> (log_ZSMC scalar, {"Xs": (B,T,N,Dx)}).
+
+        `noise` optionally injects the random draws in the HBM layout of include/psvo_hip.h:
+        eps_f (T,B,Dx,N), u_f (T,B,N) or idx_f (T,B,N) int32.
+        """
+        batch_size, time, _ = obs.shape
+        self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
+
+        log = {}
+        filt = self.SMC(hidden, obs, noise=noise)
+        log_ZSMC = self.compute_log_ZSMC(filt["lse"])
+        # (T, B, Dx, N) -> (batch_size, time, n_particles, Dx)
+        log["Xs"] = filt["Xanc"].permute(1, 0, 3, 2)
+        log["filter"] = filt
+        return log_ZSMC, log
+
+    def _desc(self, M=1):
+        H = self.model.q1_tran.Dhs[0]
+        return ops.make_desc(self.batch_size, self.time, self.n_particles, M, self.model.Dx, self.model.Dy, H,
+                             resample=self.resample_particles, two_q=self.model.use_2_q,
+                             bootstrap=self.model.use_bootstrap)
+
+    def _randn(self, *shape, device):
+        return torch.randn(*shape, device=device, dtype=torch.float32, generator=self.generator)
+
+    def _rand(self, *shape, device):
+        return torch.rand(*shape, device=device, dtype=torch.float32, generator=self.generator)
+
+    def SMC(self, hidden, obs, q_cov=1.0, noise=None):
+        """SVO.py:60-180.  Returns the kernel's output dict: X (pre-resampling, Xs_ta),
+        Xanc (X_ancestors_ta), Fm, logW (log_Ws_ta), idx, lse -- all (T, B, ...)-major."""
+        if self.q_uses_true_X:
+            # debug proposal around the true latents (SVO.py:73-77,127-131); run_flag forces it off
+            # whenever use_2_q is set (runner.py:38-39)
+            raise NotImplementedError("q_uses_true_X is a debugging aid outside the MI355X hot-path scope")
+        model = self.model
+        Dx, T, N, B = self.Dx, self.time, self.n_particles, self.batch_size
+        dev = obs.device
+        noise = noise or {}
+
+        preprocessed_X0, preprocessed_obs = self.preprocess_obs(obs)
+        self.preprocessed_X0, self.preprocessed_obs = preprocessed_X0, preprocessed_obs
+        both = model.use_bootstrap and model.use_2_q
+
+        # ---- hoisted, particle-independent terms (B*T rows) ------------------------------------
+        m0 = self.q0.mean(preprocessed_X0)                                    # (B, Dx)
+        sig0 = self.q0.get_sigma()
+        if both:
+            fm0, fsig0 = m0, sig0                                             # f_0 is q0's own density
+        else:
+            fm0, fsig0 = self.f.mean(preprocessed_X0), self.f.get_sigma()     # SVO.py:91-92
+        mu2 = sig_q2 = None
+        if model.use_2_q:
+            mu2 = self.q2.mean(preprocessed_obs).transpose(0, 1).contiguous()  # (T, B, Dx)
+            sig_q2 = self.q2.get_sigma()
+        obs_TB = obs.transpose(0, 1).contiguous().float()
+
+        eps = noise.get("eps_f")
+        if eps is None:
+            eps = self._randn(T, B, Dx, N, device=dev)
+        u, idx_in = noise.get("u_f"), noise.get("idx_f")
+        if self.resample_particles and u is None and idx_in is None:
+            u = self._rand(T, B, N, device=dev)
+
+        f_params = None if model.use_bootstrap else model.f_tran.hip_params()
+        sig_f = None if model.use_bootstrap else self.f.get_sigma()
+        with torch.no_grad():
+            filt = ops.filter_forward(
+                self._desc(), _c(model.q1_tran.hip_params()), _c(f_params), _c(model.g_tran.hip_params()),
+                _c(self.q1.get_sigma()), _c(sig_q2), _c(sig_f), _c(self.g.get_sigma()),
+                _c(mu2), _c(m0), _c(sig0), _c(fm0), _c(fsig0), obs_TB, eps, u, idx_in)
+        filt["eps"], filt["u"] = eps, u
+        return filt
+
+    def compute_log_ZSMC(self, lse):
+        """SVO.py:302-311: mean_b sum_t logsumexp_n log_Ws[t, n, b]."""
+        return ops.elbo_filter(self._desc(), lse).mean()
+
+    def preprocess_obs(self, obs):
+        """SVO.py:313-331 -> (preprocessed_X0 (B, E0), preprocessed_obs (B, T, E))."""
+        if not self.smooth_obs:
+            preprocessed_obs = obs
+            preprocessed_X0 = obs[:, 0]
+        else:
+            preprocessed_X0, preprocessed_obs = self.preprocess_obs_w_bRNN(obs)
+        if not (self.model.use_bootstrap and self.model.use_2_q):
+            preprocessed_X0 = self.model.X0_transformer(preprocessed_X0)
+        return preprocessed_X0, preprocessed_obs
+
+    def preprocess_obs_w_bRNN(self, obs):
+        """SVO.py:333-369 (use_stack_rnn): bi-LSTM encodings (B, T, 2Dh) and the X0 feature
+        concat(out[:, -1], out[:, 0]) (B, 4Dh)."""
+        y_smoother, X0_smoother = self.model.bRNN
+        outputs = y_smoother(obs)
+        preprocessed_obs = outputs
+        if self.X0_use_separate_RNN:
+            outputs = X0_smoother(obs)
+        preprocessed_X0 = torch.cat([outputs[:, -1], outputs[:, 0]], dim=-1)
+        return preprocessed_X0, preprocessed_obs
+
+    def n_step_prediction(self, n_steps, hidden, obs):
+        """SVO.py:371-404: k-step predictions from the particle mean."""
+        batch_size, time, _, _ = hidden.shape
+        assert n_steps < time, "n_steps = {} >= time".format(n_steps)
+        x_BxTmkxDz = hidden.mean(dim=2)
+        y_hat_N_BxTxDy = []
+        for k in range(n_steps):
+            y_hat_N_BxTxDy.append(self.g.mean(x_BxTmkxDz))
+            x_BxTmkxDz = self.f.mean(x_BxTmkxDz[:, :-1])
+        y_hat_N_BxTxDy.append(self.g.mean(x_BxTmkxDz))
+        y_N_BxTxDy = [obs[:, k:, :] for k in range(n_steps + 1)]
+        return y_hat_N_BxTxDy, y_N_BxTxDy
+
+    def get_nextX(self, X):
+        """SVO.py:406-409 (quiver plots)."""
+        return self.f.mean(X)
+
+
+def _c(x):
+    """detach + make contiguous fp32 (tensors or tuples of tensors); None passes through."""
+    if x is None:
+        return None
+    if isinstance(x, (tuple, list)):
+        return tuple(_c(v) for v in x)
+    return x.detach().float().contiguous()

@@ -1,0 +1,69 @@
+"""ctypes binding of libpsvo_hip.so (the C ABI declared in include/psvo_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call returns a
+non-zero status this module raises.  Nothing here imports `oracle/`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpsvo_hip.so")
+
+PSVO_OK = 0
+PSVO_ERR_INVALID = -1
+PSVO_ERR_UNSUPPORTED = -2
+PSVO_ERR_HIP = -3
+
+
+class PsvoHipError(RuntimeError):
+    """A libpsvo_hip entry point returned a non-zero status."""
+
+
+class psvo_desc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("B", "T", "N", "M", "Dx", "Dy", "H", "resample", "two_q", "bootstrap")]
+
+
+class psvo_mlp(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("W1", "b1", "W2", "b2")]
+
+
+_P = ctypes.c_void_p
+_DESC = ctypes.POINTER(psvo_desc)
+_MLP = ctypes.POINTER(psvo_mlp)
+
+# name -> (restype, argtypes); must list every symbol include/psvo_hip.h declares
+SIGNATURES = {
+    "psvo_abi_version": (ctypes.c_int, []),
+    "psvo_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "psvo_filter_forward": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 19 + [_P]),
+    "psvo_bsim_forward": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 19 + [_P]),
+    "psvo_elbo_filter": (ctypes.c_int, [_DESC, _P, _P, _P]),
+    "psvo_elbo_bsim": (ctypes.c_int, [_DESC, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PsvoHipError(
+                "libpsvo_hip.so not found at %s -- build it with `python -m psvo_amd.build` "
+                "(there is no CPU or PyTorch fallback for the PSVO hot path)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != PSVO_OK:
+        msg = load().psvo_status_string(status).decode()
+        exc = ValueError if status in (PSVO_ERR_INVALID, PSVO_ERR_UNSUPPORTED) else PsvoHipError
+        raise exc("%s failed: %s (status %d)" % (what, msg, status))

@@ -1,0 +1,54 @@
+// Small entry points of the C ABI: version/status strings and the per-sequence ELBO reductions.
+#include "common.h"
+
+namespace psvo {
+
+// out[b] = sum_t lse[t, b]   (SVO.compute_log_ZSMC before the batch mean, reference SVO.py:302-311)
+__global__ void elbo_filter_kernel(const float* __restrict__ lse, float* __restrict__ out, int T, int B) {
+    const int b = blockIdx.x;
+    float acc = 0.f;
+    for (int t = threadIdx.x; t < T; t += 64) acc += lse[(size_t)t * B + b];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) out[b] = acc;
+}
+
+// out[b] = logsumexp_n score[b, n] - log N   (PSVO.compute_log_ZSMC, reference PSVO.py:52-67)
+__global__ void elbo_bsim_kernel(const float* __restrict__ score, float* __restrict__ out, int N) {
+    const int b = blockIdx.x;
+    const float ninf = -__builtin_huge_valf();
+    float mx = ninf;
+    for (int n = threadIdx.x; n < N; n += 64) mx = fmaxf(mx, score[(size_t)b * N + n]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += 64) s += expf(score[(size_t)b * N + n] - mx);
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[b] = mx + logf(s) - logf((float)N);
+}
+
+}  // namespace psvo
+
+extern "C" int psvo_abi_version(void) { return PSVO_ABI_VERSION; }
+
+extern "C" const char* psvo_status_string(int status) {
+    switch (status) {
+        case PSVO_OK: return "ok";
+        case PSVO_ERR_INVALID: return "invalid argument (null pointer, non-positive size or inconsistent descriptor)";
+        case PSVO_ERR_UNSUPPORTED: return "unsupported configuration (Dx/Dy/H/M/N outside the instantiated kernel set)";
+        case PSVO_ERR_HIP: return "HIP runtime error at kernel launch";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int psvo_elbo_filter(const psvo_desc* desc, const float* lse, float* out, void* stream) {
+    if (!desc || !lse || !out || desc->B <= 0 || desc->T <= 0) return PSVO_ERR_INVALID;
+    hipLaunchKernelGGL(psvo::elbo_filter_kernel, dim3(desc->B), dim3(64), 0, static_cast<hipStream_t>(stream), lse,
+                       out, desc->T, desc->B);
+    return hipGetLastError() == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
+}
+
+extern "C" int psvo_elbo_bsim(const psvo_desc* desc, const float* score, float* out, void* stream) {
+    if (!desc || !score || !out || desc->B <= 0 || desc->N <= 0) return PSVO_ERR_INVALID;
+    hipLaunchKernelGGL(psvo::elbo_bsim_kernel, dim3(desc->B), dim3(64), 0, static_cast<hipStream_t>(stream), score,
+                       out, desc->N);
+    return hipGetLastError() == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
+}

@@ -1,0 +1,481 @@
+// Backward simulation with proposal (PSVO): restates PSVO.backward_simulation_w_proposal
+// (reference src/SMC/PSVO.py:69-203) -- see include/psvo_hip.h for the contract.
+//
+// Work decomposition (MI355X).  The B*N backward chains never interact (PSVO.py:116-151); each
+// chain step draws M sub-particles and needs, for each, logsumexp_j over ALL N forward particles
+// of the transition log-density (the reference's (M, N, N, B) tile, PSVO.py:128-133).
+//   * workgroup = 256 lanes = 256/M chains of ONE sequence b, persistent over t = T-1 .. 0;
+//   * lane = (chain, sub-particle m): the lane owns proposal m (sampling, MLP_f, MLP_g);
+//   * the pair loop is register-blocked over the lane's QUAD: the four lanes of a quad hold four
+//     consecutive m; each lane walks the forward particles j = q, q+4, ... (q = quad lane) and
+//     evaluates all four m of its quad against each j, so one 16-byte LDS broadcast read feeds
+//     four pairs.  Partial (max, sum) pairs are merged across the quad with two xor-shuffles.
+//   * the forward tile of step t-1 -- F'_j = MLP_f(X_{t-1}[j]) * r and W'_j = normalised log
+//     weight, both pre-scaled into the log2 domain -- is staged in LDS (N * 16 B; 2 KB at N=128),
+//     double-buffered, prefetched from HBM one step ahead.  The tile is never materialised.
+//   * pair arithmetic: v = W'_j - sum_d (x'_d - F'_jd)^2  (log2 domain), online log-sum-exp in
+//     chunks of four j.
+#include "common.h"
+
+namespace psvo {
+
+struct BsimArgs {
+    int B, T, N;
+    int two_q_unused;
+    psvo_mlp f, g, q1inv;
+    const float *X, *Fm, *logW, *lse;
+    const float *sig_f, *sig_g, *sig_q1inv, *sig_bq2;
+    const float *bmu2, *minit, *sig_init, *imean, *isig;
+    const float *obs, *eps_b, *u_b;
+    const int32_t* sel_in;
+    float *bwX, *flp, *glp, *Omega;
+    int32_t* sel_out;
+    float* score;
+};
+
+template <int DX>
+struct TileSlot {
+    static constexpr int kFloats = (DX <= 3) ? 4 : 8;
+};
+
+__device__ __forceinline__ float quad_bcast(float v, int lane, int i) { return __shfl(v, (lane & ~3) | i); }
+
+// merge two online-lse states kept in the log2 domain
+__device__ __forceinline__ void lse2_merge(float& m, float& s, float m2, float s2) {
+    const float nm = fmaxf(m, m2);
+    // guard -inf - -inf
+    const float a = (m == nm) ? 1.f : exp2_fast(m - nm);
+    const float b = (m2 == nm) ? 1.f : exp2_fast(m2 - nm);
+    s = s * a + s2 * b;
+    m = nm;
+}
+
+template <int DX, int DY, int H, int M>
+__global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    constexpr int PS = TileSlot<DX>::kFloats;
+    constexpr int kMaxStage = 4;
+    constexpr bool kRolled = (2 * MQ::kSize + MG::kSize) > 330;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int NTB = blockDim.x;
+    const int B = a.B, T = a.T, N = a.N;
+    const int NP = (N + 3) & ~3;
+    const int b = blockIdx.y;
+    const int cpb = NTB / M;
+    const int cl = tid / M, m = tid % M, q = m & 3;
+    const int n_raw = blockIdx.x * cpb + cl;
+    const bool valid = n_raw < N;
+    const int n = valid ? n_raw : N - 1;
+    const int gbase = lane - m;  // first lane of this chain's M-lane group inside the wave
+
+    float* wf = smem;
+    float* wg = wf + MQ::kSize;
+    float* wqi = wg + MG::kSize;
+    float* tile = wqi + MQ::kSize;  // 2 buffers of NP * PS floats
+
+    MQ::load(wf, a.f, tid, NTB);
+    MG::load(wg, a.g, tid, NTB);
+    MQ::load(wqi, a.q1inv, tid, NTB);
+
+    // ---- constants --------------------------------------------------------------------------
+    float isf[DX], rp[DX], isg[DY];
+    float kf = -DX * kHalfLog2Pi, kg = -DY * kHalfLog2Pi;
+    const float rscale = sqrtf(0.5f * kLog2e);
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        const float s = a.sig_f[d];
+        isf[d] = 1.f / s;
+        rp[d] = isf[d] * rscale;  // (x' - F')^2 summed == 0.5*log2e*sum(((x-F)/s)^2)
+        kf -= logf(s);
+    }
+#pragma unroll
+    for (int e = 0; e < DY; ++e) {
+        const float s = a.sig_g[e];
+        isg[e] = 1.f / s;
+        kg -= logf(s);
+    }
+    // PoG(q1_inv, BSim_q2) on scales (SVO.py:186-197 as called from PSVO.py:120-122)
+    float pc[DX], pic[DX], pi1[DX], pi2[DX];
+    float kq = -DX * kHalfLog2Pi;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        pi1[d] = 1.f / a.sig_q1inv[d];
+        pi2[d] = 1.f / a.sig_bq2[d];
+        pic[d] = pi1[d] + pi2[d];
+        pc[d] = 1.f / pic[d];
+        kq -= logf(pc[d]);
+    }
+    // q_init (t = T-1) and the t = 0 "filter" term
+    float s_init[DX], is_init[DX], i_isig[DX], im[DX], mi[DX];
+    float kinit = -DX * kHalfLog2Pi, kiota = -DX * kHalfLog2Pi;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        s_init[d] = a.sig_init[d];
+        is_init[d] = 1.f / s_init[d];
+        kinit -= logf(s_init[d]);
+        i_isig[d] = 1.f / a.isig[d];
+        kiota -= logf(a.isig[d]);
+        im[d] = a.imean[b * DX + d];
+        mi[d] = a.minit[b * DX + d];
+    }
+    const float logM = logf((float)M);
+    const float ninf = -__builtin_huge_valf();
+
+    // ---- forward-tile staging -----------------------------------------------------------------
+    float st[kMaxStage][DX + 1];
+    auto stage_load = [&](int tt) {  // global -> registers, forward step tt
+        const size_t tb = (size_t)tt * B + b;
+        const float l = a.lse[tb];
+#pragma unroll
+        for (int r = 0; r < kMaxStage; ++r) {
+            const int j = tid + r * NTB;
+            if (j < NP) {
+                const int jc = j < N ? j : N - 1;
+#pragma unroll
+                for (int d = 0; d < DX; ++d) st[r][d] = a.Fm[(tb * DX + d) * N + jc] * rp[d];
+                st[r][DX] = j < N ? (a.logW[tb * N + jc] - l) * kLog2e : ninf;
+            }
+        }
+    };
+    auto stage_store = [&](float* buf) {  // registers -> LDS
+#pragma unroll
+        for (int r = 0; r < kMaxStage; ++r) {
+            const int j = tid + r * NTB;
+            if (j < NP) {
+                if constexpr (DX <= 3) {
+                    float4 v;
+                    v.x = st[r][0];
+                    v.y = DX > 1 ? st[r][DX > 1 ? 1 : 0] : 0.f;
+                    v.z = DX > 2 ? st[r][DX > 2 ? 2 : 0] : 0.f;
+                    v.w = st[r][DX];
+                    *reinterpret_cast<float4*>(buf + j * PS) = v;
+                } else {
+                    *reinterpret_cast<float4*>(buf + j * PS) = make_float4(st[r][0], st[r][1], st[r][2], st[r][3]);
+                    *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(st[r][4], 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    };
+
+    if (T >= 2) {
+        stage_load(T - 2);
+        stage_store(tile);
+    }
+
+    // ---- per-step inputs, prefetched one step ahead ----------------------------------------------
+    float eps_c[DX], bmu_c[DX], obs_c[DY], u_c = 0.f;
+    int sel_c = 0;
+    auto load_inputs = [&](int t, float (&e)[DX], float (&bm)[DX], float (&o)[DY], float& uu, int& ss) {
+        const size_t tb = (size_t)t * B + b;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            e[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
+            bm[d] = a.bmu2[tb * DX + d];
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) o[k] = a.obs[tb * DY + k];
+        if (a.sel_in) ss = a.sel_in[tb * N + n];
+        else uu = a.u_b[tb * N + n];
+    };
+    load_inputs(T - 1, eps_c, bmu_c, obs_c, u_c, sel_c);
+    __syncthreads();
+
+    float xp[DX];  // x_{t+1} of this chain (same in all M lanes)
+#pragma unroll
+    for (int d = 0; d < DX; ++d) xp[d] = 0.f;
+    float score = 0.f;
+
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t tb = (size_t)t * B + b;
+        const float* cur = tile + ((T - 1 - t) & 1) * NP * PS;
+        float* nxt = tile + ((T - t) & 1) * NP * PS;
+        const bool last = (t == T - 1);
+
+        float eps_n[DX], bmu_n[DX], obs_n[DY], u_n = 0.f;
+        int sel_n = 0;
+        if (t >= 1) load_inputs(t - 1, eps_n, bmu_n, obs_n, u_n, sel_n);
+        if (t >= 2) stage_load(t - 2);
+
+        // ---- proposal ---------------------------------------------------------------------------
+        float x[DX], q_lp;
+        if (last) {
+            float mu[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                mu[d] = mi[d];
+                x[d] = fmaf(s_init[d], eps_c[d], mu[d]);
+            }
+            q_lp = diag_lp<DX>(x, mu, is_init, kinit);
+        } else {
+            float m1[DX], mu[DX];
+            MQ::template eval<kRolled>(wqi, xp, m1);
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                mu[d] = pc[d] * fmaf(pi1[d], m1[d], pi2[d] * bmu_c[d]);
+                x[d] = fmaf(pc[d], eps_c[d], mu[d]);
+            }
+            q_lp = diag_lp<DX>(x, mu, pic, kq);
+        }
+
+        // ---- f(x_{t+1} | x~), g(y_t | x~) ------------------------------------------------------------
+        float phi = 0.f;
+        if (!last) {
+            float fmx[DX];
+            MQ::template eval<kRolled>(wf, x, fmx);
+            phi = diag_lp<DX>(xp, fmx, isf, kf);
+        }
+        float gm[DY];
+        MG::template eval<kRolled>(wg, x, gm);
+        const float g_lp = diag_lp<DY>(obs_c, gm, isg, kg);
+
+        // ---- filter term: logsumexp_j( log f(x~ | X_{t-1}[j]) + W^_{t-1}[j] ) -----------------------
+        float lam;
+        if (t >= 1) {
+            float xq[4][DX];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int d = 0; d < DX; ++d) xq[i][d] = quad_bcast(x[d] * rp[d], lane, i);
+            float mx[4], sm[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                mx[i] = ninf;
+                sm[i] = 0.f;
+            }
+            // lane walks j = q, q+4, ...; chunks of 4 such j per online-lse update
+            const int nq = NP >> 2;  // entries per quad lane
+            int jj = 0;
+            for (; jj + 4 <= nq; jj += 4) {
+                float v[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float* p = cur + ((jj + c) * 4 + q) * PS;
+                    float F[DX], W;
+                    if constexpr (DX <= 3) {
+                        const float4 e = *reinterpret_cast<const float4*>(p);
+                        F[0] = e.x;
+                        if (DX > 1) F[DX > 1 ? 1 : 0] = e.y;
+                        if (DX > 2) F[DX > 2 ? 2 : 0] = e.z;
+                        W = e.w;
+                    } else {
+                        const float4 e = *reinterpret_cast<const float4*>(p);
+                        F[0] = e.x; F[1] = e.y; F[2] = e.z; F[3] = e.w;
+                        W = p[4];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float acc = W;
+#pragma unroll
+                        for (int d = 0; d < DX; ++d) {
+                            const float df = xq[i][d] - F[d];
+                            acc = fmaf(-df, df, acc);
+                        }
+                        v[i][c] = acc;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float cm = fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3]));
+                    const float nm = fmaxf(mx[i], cm);
+                    // nm == -inf only if every term so far is -inf: keep s = 0 without NaNs
+                    const float base = (nm == ninf) ? 0.f : nm;
+                    float s = sm[i] * exp2_fast(mx[i] - base);
+                    s += exp2_fast(v[i][0] - base);
+                    s += exp2_fast(v[i][1] - base);
+                    s += exp2_fast(v[i][2] - base);
+                    s += exp2_fast(v[i][3] - base);
+                    sm[i] = s;
+                    mx[i] = nm;
+                }
+            }
+            for (; jj < nq; ++jj) {  // remainder entries
+                const float* p = cur + (jj * 4 + q) * PS;
+                float F[DX], W;
+                if constexpr (DX <= 3) {
+                    const float4 e = *reinterpret_cast<const float4*>(p);
+                    F[0] = e.x;
+                    if (DX > 1) F[DX > 1 ? 1 : 0] = e.y;
+                    if (DX > 2) F[DX > 2 ? 2 : 0] = e.z;
+                    W = e.w;
+                } else {
+                    const float4 e = *reinterpret_cast<const float4*>(p);
+                    F[0] = e.x; F[1] = e.y; F[2] = e.z; F[3] = e.w;
+                    W = p[4];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float acc = W;
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) {
+                        const float df = xq[i][d] - F[d];
+                        acc = fmaf(-df, df, acc);
+                    }
+                    const float nm = fmaxf(mx[i], acc);
+                    const float base = (nm == ninf) ? 0.f : nm;
+                    sm[i] = sm[i] * exp2_fast(mx[i] - base) + exp2_fast(acc - base);
+                    mx[i] = nm;
+                }
+            }
+            // merge the four j-slices of the quad; lane q keeps sub-particle i == q
+            float lm = ninf, ls = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float mm = mx[i], ss = sm[i];
+                lse2_merge(mm, ss, __shfl_xor(mx[i], 1), __shfl_xor(sm[i], 1));
+                const float m2 = __shfl_xor(mm, 2), s2 = __shfl_xor(ss, 2);
+                lse2_merge(mm, ss, m2, s2);
+                if (i == q) {
+                    lm = mm;
+                    ls = ss;
+                }
+            }
+            lam = fmaf(kLn2, lm + log2_fast(ls), kf);
+        } else {
+            lam = diag_lp<DX>(x, im, i_isig, kiota);  // t = 0: q0 / f density at mu_0 (PSVO.py:169-175)
+        }
+
+        // ---- omega, normalise over the M sub-particles, draw one ---------------------------------------
+        const float om_raw = lam + phi + g_lp - q_lp;
+        float omx = om_raw;
+#pragma unroll
+        for (int o = 1; o < M; o <<= 1) omx = fmaxf(omx, __shfl_xor(omx, o));
+        const float pw = expf(om_raw - omx);
+        float cdfv = pw;  // inclusive scan across the chain's M lanes
+#pragma unroll
+        for (int o = 1; o < M; o <<= 1) {
+            const float tv = __shfl_up(cdfv, o);
+            if (m >= o) cdfv += tv;
+        }
+        const float total = __shfl(cdfv, gbase + M - 1);
+        const float omega = om_raw - (omx + logf(total));
+        int sel;
+        if (a.sel_in) {
+            sel = sel_c;
+        } else {
+            const unsigned long long bal = __ballot(cdfv <= u_c * total);
+            const unsigned long long mask = (M == 64) ? ~0ull : (((1ull << M) - 1ull) << gbase);
+            sel = min((int)__popcll(bal & mask), M - 1);
+        }
+        const int src = gbase + sel;
+        float xs[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) xs[d] = __shfl(x[d], src);
+        const float om_s = __shfl(omega, src);
+        const float phi_s = __shfl(phi, src);
+        const float g_s = __shfl(g_lp, src);
+        const float q_s = __shfl(q_lp, src);
+        const float lam_s = __shfl(lam, src);
+        const float Om = om_s + q_s + logM;
+
+        if (valid && m == 0) {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) a.bwX[(tb * DX + d) * N + n] = xs[d];
+            a.glp[tb * N + n] = g_s;
+            a.Omega[tb * N + n] = Om;
+            a.sel_out[tb * N + n] = sel;
+            if (!last) a.flp[(tb + B) * N + n] = phi_s;     // f_log_probs[t+1]
+            if (t == 0) a.flp[(size_t)b * N + n] = lam_s;   // f_log_probs[0] = f_init
+        }
+        score += g_s - Om + (last ? 0.f : phi_s) + (t == 0 ? lam_s : 0.f);
+
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            xp[d] = xs[d];
+            eps_c[d] = eps_n[d];
+            bmu_c[d] = bmu_n[d];
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) obs_c[k] = obs_n[k];
+        u_c = u_n;
+        sel_c = sel_n;
+
+        if (t >= 2) stage_store(nxt);
+        __syncthreads();
+    }
+    if (valid && m == 0) a.score[(size_t)b * N + n] = score;
+}
+
+template <int DX, int DY, int H, int M>
+static int launch_bsim(const BsimArgs& a, hipStream_t stream) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    constexpr int PS = TileSlot<DX>::kFloats;
+    const int NP = (a.N + 3) & ~3;
+    int NTB = ((a.N * M + 63) / 64) * 64;
+    if (NTB > 256) NTB = 256;
+    const int cpb = NTB / M;
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS);
+    dim3 grid((a.N + cpb - 1) / cpb, a.B);
+    hipLaunchKernelGGL((bsim_fwd_kernel<DX, DY, H, M>), grid, dim3(NTB), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
+}
+
+template <int DX, int DY, int H>
+static int bsim_dispatch_m(const BsimArgs& a, int M, hipStream_t s) {
+    switch (M) {
+        case 4: return launch_bsim<DX, DY, H, 4>(a, s);
+        case 8: return launch_bsim<DX, DY, H, 8>(a, s);
+        case 16: return launch_bsim<DX, DY, H, 16>(a, s);
+        case 32: return launch_bsim<DX, DY, H, 32>(a, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+template <int DX, int DY>
+static int bsim_dispatch_h(const BsimArgs& a, int H, int M, hipStream_t s) {
+    switch (H) {
+        case 16: return bsim_dispatch_m<DX, DY, 16>(a, M, s);
+        case 32: return bsim_dispatch_m<DX, DY, 32>(a, M, s);
+        case 64: return bsim_dispatch_m<DX, DY, 64>(a, M, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+template <int DX>
+static int bsim_dispatch_dy(const BsimArgs& a, int Dy, int H, int M, hipStream_t s) {
+    switch (Dy) {
+        case 1: return bsim_dispatch_h<DX, 1>(a, H, M, s);
+        case 2: return bsim_dispatch_h<DX, 2>(a, H, M, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace psvo
+
+extern "C" int psvo_bsim_forward(const psvo_desc* desc, const float* X, const float* Fm, const float* logW,
+                                 const float* lse, const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
+                                 const float* sig_f, const float* sig_g, const float* sig_q1inv,
+                                 const float* sig_bq2, const float* bmu2, const float* minit,
+                                 const float* sig_init, const float* imean, const float* isig, const float* obs,
+                                 const float* eps_b, const float* u_b, const int32_t* sel_in, float* bwX,
+                                 float* flp, float* glp, float* Omega, int32_t* sel_out, float* score,
+                                 void* stream) {
+    using namespace psvo;
+    if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 ||
+        !bmu2 || !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwX || !flp || !glp || !Omega ||
+        !sel_out || !score)
+        return PSVO_ERR_INVALID;
+    if (!u_b && !sel_in) return PSVO_ERR_INVALID;
+    if (desc->B <= 0 || desc->T < 2 || desc->N <= 0 || desc->M <= 0) return PSVO_ERR_INVALID;
+    if (desc->N > 1024 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
+    (void)X;
+
+    BsimArgs a;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N; a.two_q_unused = 0;
+    a.f = *f; a.g = *g; a.q1inv = *q1_inv;
+    a.X = X; a.Fm = Fm; a.logW = logW; a.lse = lse;
+    a.sig_f = sig_f; a.sig_g = sig_g; a.sig_q1inv = sig_q1inv; a.sig_bq2 = sig_bq2;
+    a.bmu2 = bmu2; a.minit = minit; a.sig_init = sig_init; a.imean = imean; a.isig = isig;
+    a.obs = obs; a.eps_b = eps_b; a.u_b = u_b; a.sel_in = sel_in;
+    a.bwX = bwX; a.flp = flp; a.glp = glp; a.Omega = Omega; a.sel_out = sel_out; a.score = score;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (desc->Dx) {
+        case 2: return bsim_dispatch_dy<2>(a, desc->Dy, desc->H, desc->M, s);
+        case 3: return bsim_dispatch_dy<3>(a, desc->Dy, desc->H, desc->M, s);
+        case 4: return bsim_dispatch_dy<4>(a, desc->Dy, desc->H, desc->M, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}

@@ -1,0 +1,138 @@
+// Device-side helpers shared by the filter and backward-simulation kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/psvo_hip.h"
+
+namespace psvo {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kHalfLog2Pi = 0.9189385332046727f;
+constexpr int kWave = 64;
+
+// v_exp_f32 / v_log_f32 are base-2 on CDNA; keep hot loops in the log2 domain.
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }
+
+// ---------------------------------------------------------------------------------------------
+// One-hidden-layer MLP with weights staged in LDS, read as wave-uniform float4 broadcasts.
+// LDS image: W1[DIN][H] | b1[H] | W2T[DOUT][H] | b2[DOUT padded to 4]
+// ---------------------------------------------------------------------------------------------
+template <int DIN, int H, int DOUT>
+struct MlpLds {
+    static constexpr int kW1 = 0;
+    static constexpr int kB1 = DIN * H;
+    static constexpr int kW2 = kB1 + H;
+    static constexpr int kB2 = kW2 + DOUT * H;
+    static constexpr int kSize = kB2 + ((DOUT + 3) & ~3);
+
+    // cooperative load by the whole block; caller syncs afterwards
+    __device__ static void load(float* __restrict__ w, const psvo_mlp& p, int tid, int nthreads) {
+        for (int i = tid; i < DIN * H; i += nthreads) w[kW1 + i] = p.W1[i];
+        for (int i = tid; i < H; i += nthreads) w[kB1 + i] = p.b1[i];
+        for (int i = tid; i < DOUT * H; i += nthreads) {
+            const int o = i / H, k = i - o * H;
+            w[kW2 + i] = p.W2[k * DOUT + o];
+        }
+        for (int i = tid; i < ((DOUT + 3) & ~3); i += nthreads) w[kB2 + i] = i < DOUT ? p.b2[i] : 0.f;
+    }
+
+    // four hidden units: h = relu(x W1[:, k:k+4] + b1[k:k+4]); out += h W2[k:k+4, :]
+    __device__ __forceinline__ static void group4(const float* __restrict__ w, int k, const float (&x)[DIN],
+                                                  float (&out)[DOUT]) {
+        float4 h = *reinterpret_cast<const float4*>(w + kB1 + k);
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) {
+            const float4 wi = *reinterpret_cast<const float4*>(w + kW1 + i * H + k);
+            h.x = fmaf(x[i], wi.x, h.x);
+            h.y = fmaf(x[i], wi.y, h.y);
+            h.z = fmaf(x[i], wi.z, h.z);
+            h.w = fmaf(x[i], wi.w, h.w);
+        }
+        h.x = fmaxf(h.x, 0.f);
+        h.y = fmaxf(h.y, 0.f);
+        h.z = fmaxf(h.z, 0.f);
+        h.w = fmaxf(h.w, 0.f);
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) {
+            const float4 wo = *reinterpret_cast<const float4*>(w + kW2 + o * H + k);
+            out[o] = fmaf(h.x, wo.x, out[o]);
+            out[o] = fmaf(h.y, wo.y, out[o]);
+            out[o] = fmaf(h.z, wo.z, out[o]);
+            out[o] = fmaf(h.w, wo.w, out[o]);
+        }
+    }
+
+    // out = relu(x W1 + b1) W2 + b2, hidden units accumulated in k order.
+    // ROLLED = false: fully unrolled (the compiler may keep loop-invariant weights in VGPRs);
+    // ROLLED = true : a real loop over groups of 8 hidden units (bounded register pressure).
+    template <bool ROLLED = false>
+    __device__ __forceinline__ static void eval(const float* __restrict__ w, const float (&x)[DIN],
+                                                float (&out)[DOUT]) {
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) out[o] = w[kB2 + o];
+        if constexpr (ROLLED && (H % 8 == 0) && (H > 8)) {
+#pragma unroll 1
+            for (int k = 0; k < H; k += 8) {
+                group4(w, k, x, out);
+                group4(w, k + 4, x, out);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < H; k += 4) group4(w, k, x, out);
+        }
+    }
+};
+
+// diagonal-Gaussian log density given inverse scales and the constant -sum(log s) - D/2 log 2pi
+template <int D>
+__device__ __forceinline__ float diag_lp(const float (&x)[D], const float (&mu)[D], const float (&inv_s)[D],
+                                         float cst) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float z = (x[d] - mu[d]) * inv_s[d];
+        acc = fmaf(z, z, acc);
+    }
+    return fmaf(-0.5f, acc, cst);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block collectives (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// block-wide max / sum over `nw` waves; `red` is >= 2*16 floats of LDS scratch.
+// Each call uses its own half of `red` selected by `slot` so two back-to-back calls need one
+// barrier each.
+__device__ __forceinline__ float block_max(float v, float* red, int slot, int wave, int lane, int nw) {
+    v = wave_max(v);
+    if (nw == 1) return v;
+    float* r = red + slot * 16;
+    if (lane == 0) r[wave] = v;
+    __syncthreads();
+    float m = r[0];
+    for (int i = 1; i < nw; ++i) m = fmaxf(m, r[i]);
+    return m;
+}
+
+}  // namespace psvo

@@ -1,0 +1,345 @@
+// Forward particle filter: one persistent workgroup per sequence, time loop in-kernel.
+// Restates SVO.SMC (reference src/SMC/SVO.py:60-180) -- see include/psvo_hip.h for the contract.
+//
+// Work decomposition (MI355X): lane = particle n, workgroup = sequence b.  Everything inside a
+// step is per-lane except the log-sum-exp over particles and the multinomial draw, which are a
+// wavefront shuffle reduction/scan plus one LDS hop across the <= 16 waves of the workgroup.
+// MLP weights live in LDS and are read as wave-uniform float4 broadcasts.  In bootstrap mode the
+// proposal mean of a resampled particle is MLP_f(X_t[a]) = Fm_t[a], so the transition MLP is
+// evaluated once per pre-resampling particle and *gathered* together with the particle instead
+// of being re-evaluated after the gather (halves the dependent MLP chain per step).
+#include "common.h"
+
+namespace psvo {
+
+struct FilterArgs {
+    int B, T, N;
+    int resample, two_q, bootstrap;
+    psvo_mlp q1, f, g;
+    const float *sig_q1, *sig_q2, *sig_f, *sig_g;
+    const float *mu2, *m0, *sig0, *fm0, *fsig0, *obs, *eps, *u;
+    const int32_t* idx_in;
+    float *X, *Xanc, *Fm, *logW;
+    int32_t* idx_out;
+    float* lse;
+};
+
+template <int DX>
+struct StepK {
+    float c[DX];    // proposal scale
+    float ic[DX];   // 1 / c
+    float i1[DX];   // 1 / s1
+    float i2[DX];   // 1 / s2 (two_q)
+    float ifs[DX];  // 1 / transition scale
+    float lq, lf;   // -sum(log scale) - D/2 log(2 pi) of proposal / transition
+};
+
+template <int DX>
+__device__ __forceinline__ StepK<DX> make_stepk(const float* s1, const float* s2, const float* fs, bool two_q) {
+    StepK<DX> K;
+    float lq = -DX * kHalfLog2Pi, lf = -DX * kHalfLog2Pi;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        K.i1[d] = 1.f / s1[d];
+        if (two_q) {
+            K.i2[d] = 1.f / s2[d];
+            K.ic[d] = K.i1[d] + K.i2[d];
+            K.c[d] = 1.f / K.ic[d];
+        } else {
+            K.i2[d] = 0.f;
+            K.ic[d] = K.i1[d];
+            K.c[d] = s1[d];
+        }
+        K.ifs[d] = 1.f / fs[d];
+        lq -= logf(K.c[d]);
+        lf -= logf(fs[d]);
+    }
+    K.lq = lq;
+    K.lf = lf;
+    return K;
+}
+
+template <int DX, int DY, int H, int MAXT>
+__global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = blockDim.x, nw = NT >> 6;
+    const int b = blockIdx.x, B = a.B, T = a.T, N = a.N;
+    const bool valid = tid < N;
+    const int n = valid ? tid : N - 1;  // clamp so that loads stay in bounds
+
+    float* wq1 = smem;
+    float* wf = wq1 + MQ::kSize;
+    float* wg = wf + MQ::kSize;
+    float* cdf = wg + MG::kSize;
+    float* sx = cdf + NT;          // [DX][NT] staged X_t
+    float* sp = sx + DX * NT;      // [DX][NT] staged MLP_q1(X_t)
+    float* sf = sp + DX * NT;      // [DX][NT] staged MLP_f(X_t) (== sp when bootstrap)
+    float* red = sf + DX * NT;     // 48 floats scratch
+
+    MQ::load(wq1, a.q1, tid, NT);
+    if (!a.bootstrap) MQ::load(wf, a.f, tid, NT);
+    MG::load(wg, a.g, tid, NT);
+    const float* wfm = a.bootstrap ? wq1 : wf;
+
+    // step constants: t = 0 uses (q0, sigma_q0) for the first proposal term
+    float sq1[DX], sq2[DX], sfv[DX], s0[DX], fs0[DX], isg[DY];
+    float lg = -DY * kHalfLog2Pi;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        sq1[d] = a.sig_q1[d];
+        sq2[d] = a.two_q ? a.sig_q2[d] : 1.f;
+        sfv[d] = a.bootstrap ? a.sig_q1[d] : a.sig_f[d];
+        s0[d] = a.sig0[d];
+        fs0[d] = a.fsig0[d];
+    }
+#pragma unroll
+    for (int e = 0; e < DY; ++e) {
+        const float s = a.sig_g[e];
+        isg[e] = 1.f / s;
+        lg -= logf(s);
+    }
+    const StepK<DX> K0 = make_stepk<DX>(s0, sq2, fs0, a.two_q != 0);
+    const StepK<DX> K1 = make_stepk<DX>(sq1, sq2, sfv, a.two_q != 0);
+    const float neg_logN = -logf((float)N);
+    const float ninf = -__builtin_huge_valf();
+
+    float mean1[DX], fmean[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        mean1[d] = a.m0[b * DX + d];
+        fmean[d] = a.fm0[b * DX + d];
+    }
+    float lnw = neg_logN;
+
+    // software prefetch of the next step's inputs
+    float eps_c[DX], mu2_c[DX], obs_c[DY], u_c = 0.f;
+    int idx_c = 0;
+    auto load_inputs = [&](int t, float (&e)[DX], float (&m)[DX], float (&o)[DY], float& uu, int& ii) {
+        const size_t tb = (size_t)t * B + b;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            e[d] = a.eps[(tb * DX + d) * N + n];
+            m[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) o[k] = a.obs[tb * DY + k];
+        if (a.resample) {
+            if (a.idx_in) ii = a.idx_in[tb * N + n];
+            else uu = a.u[tb * N + n];
+        }
+    };
+    load_inputs(0, eps_c, mu2_c, obs_c, u_c, idx_c);
+    __syncthreads();  // weights visible
+
+    // Weights are loop-invariant LDS reads: when they fit the register budget the compiler keeps
+    // them all resident in VGPRs (no LDS traffic in the MLPs); otherwise make the LDS offset
+    // opaque per step so they are re-read as broadcasts instead of being spilled to scratch.
+    constexpr int kWeights = MQ::kSize + MG::kSize;
+    constexpr bool kOpaque = (MAXT > 256) ? (kWeights > 120) : (kWeights > 330);
+
+    for (int t = 0; t < T; ++t) {
+        const size_t tb = (size_t)t * B + b;
+        const StepK<DX> K = (t == 0) ? K0 : K1;
+        int zo = 0;
+        if (kOpaque) asm volatile("" : "+v"(zo));
+        const float* wq1_t = wq1 + zo;
+        const float* wfm_t = wfm + zo;
+        const float* wg_t = wg + zo;
+
+        float eps_n[DX], mu2_n[DX], obs_n[DY], u_n = 0.f;
+        int idx_n = 0;
+        if (t + 1 < T) load_inputs(t + 1, eps_n, mu2_n, obs_n, u_n, idx_n);
+
+        // ---- proposal: product of two diagonal Gaussians on *scales* (SVO.py:186-197) ----------
+        float mu[DX], x[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            mu[d] = a.two_q ? K.c[d] * fmaf(K.i1[d], mean1[d], K.i2[d] * mu2_c[d]) : mean1[d];
+            x[d] = fmaf(K.c[d], eps_c[d], mu[d]);
+        }
+        const float q_lp = diag_lp<DX>(x, mu, K.ic, K.lq);
+        const float f_lp = diag_lp<DX>(x, fmean, K.ifs, K.lf);
+
+        // ---- emission ------------------------------------------------------------------------
+        float gm[DY];
+        MG::template eval<kOpaque>(wg_t, x, gm);
+        const float g_lp = diag_lp<DY>(obs_c, gm, isg, lg);
+
+        float lw = f_lp + g_lp - q_lp + lnw;
+        if (!valid) lw = ninf;
+
+        // ---- next-step proposal / transition means of every pre-resampling particle -----------
+        float p1[DX], fm[DX];
+        MQ::template eval<kOpaque>(wq1_t, x, p1);
+        if (a.bootstrap) {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) fm[d] = p1[d];
+        } else {
+            MQ::template eval<kOpaque>(wfm_t, x, fm);
+        }
+        if (valid) {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                a.X[(tb * DX + d) * N + n] = x[d];
+                a.Fm[(tb * DX + d) * N + n] = fm[d];
+            }
+            a.logW[tb * N + n] = lw;
+        }
+
+        // ---- log-sum-exp over particles and multinomial ancestors (SVO.py:266-300) -------------
+        const float mx = block_max(lw, red, 0, wave, lane, nw);
+        const float w = valid ? expf(lw - mx) : 0.f;
+        float sc = wave_incl_scan(w, lane);
+        float total;
+        if (nw > 1) {
+            float* wt = red + 32;
+            if (lane == 63) wt[wave] = sc;
+            __syncthreads();
+            float off = 0.f, tot = 0.f;
+            for (int i = 0; i < nw; ++i) {
+                const float v = wt[i];
+                if (i < wave) off += v;
+                tot += v;
+            }
+            sc += off;
+            total = tot;
+        } else {
+            total = __shfl(sc, 63);
+        }
+        const float lse_t = mx + logf(total);
+        if (tid == 0) a.lse[tb] = lse_t;
+
+        if (a.resample) {
+            cdf[tid] = sc;
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                sx[d * NT + tid] = x[d];
+                sp[d * NT + tid] = p1[d];
+                if (!a.bootstrap) sf[d * NT + tid] = fm[d];
+            }
+            __syncthreads();
+            int idx;
+            if (a.idx_in) {
+                idx = idx_c;
+            } else {
+                // count of cdf entries <= u * total (cdf is non-decreasing)
+                const float target = u_c * total;
+                int pos = 0;
+                for (int s = 1 << (31 - __clz(N)); s > 0; s >>= 1) {
+                    const int p = pos + s;
+                    if (p <= N && cdf[p - 1] <= target) pos = p;
+                }
+                idx = min(pos, N - 1);
+            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                x[d] = sx[d * NT + idx];
+                mean1[d] = sp[d * NT + idx];
+                fmean[d] = a.bootstrap ? mean1[d] : sf[d * NT + idx];
+            }
+            if (valid) {
+                a.idx_out[tb * N + n] = idx;
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.Xanc[(tb * DX + d) * N + n] = x[d];
+            }
+            lnw = neg_logN;
+            __syncthreads();  // staged tiles are rewritten next step
+        } else {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                mean1[d] = p1[d];
+                fmean[d] = fm[d];
+            }
+            if (valid) {
+                a.idx_out[tb * N + n] = n;
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.Xanc[(tb * DX + d) * N + n] = x[d];
+            }
+            lnw = lw - lse_t;
+            if (nw > 1) __syncthreads();  // red[] reuse
+        }
+
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            eps_c[d] = eps_n[d];
+            mu2_c[d] = mu2_n[d];
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) obs_c[k] = obs_n[k];
+        u_c = u_n;
+        idx_c = idx_n;
+    }
+}
+
+template <int DX, int DY, int H>
+static int launch_filter(const FilterArgs& a, hipStream_t stream) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    const int NT = (a.N + 63) & ~63;
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + NT + 3 * DX * NT + 48);
+    // the register budget follows the workgroup size: <= 256 threads is one wave per SIMD, so
+    // the compiler may keep every MLP weight resident in VGPRs
+    if (NT <= 256)
+        hipLaunchKernelGGL((filter_fwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, a);
+    else
+        hipLaunchKernelGGL((filter_fwd_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
+}
+
+template <int DX, int DY>
+static int dispatch_h(const FilterArgs& a, int H, hipStream_t s) {
+    switch (H) {
+        case 16: return launch_filter<DX, DY, 16>(a, s);
+        case 32: return launch_filter<DX, DY, 32>(a, s);
+        case 64: return launch_filter<DX, DY, 64>(a, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+template <int DX>
+static int dispatch_dy(const FilterArgs& a, int Dy, int H, hipStream_t s) {
+    switch (Dy) {
+        case 1: return dispatch_h<DX, 1>(a, H, s);
+        case 2: return dispatch_h<DX, 2>(a, H, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace psvo
+
+extern "C" int psvo_filter_forward(const psvo_desc* desc, const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
+                                   const float* sig_q1, const float* sig_q2, const float* sig_f,
+                                   const float* sig_g, const float* mu2, const float* m0, const float* sig0,
+                                   const float* fm0, const float* fsig0, const float* obs, const float* eps,
+                                   const float* u, const int32_t* idx_in, float* X, float* Xanc, float* Fm,
+                                   float* logW, int32_t* idx_out, float* lse, void* stream) {
+    using namespace psvo;
+    if (!desc || !q1 || !g || !sig_q1 || !sig_g || !m0 || !sig0 || !fm0 || !fsig0 || !obs || !eps || !X ||
+        !Xanc || !Fm || !logW || !idx_out || !lse)
+        return PSVO_ERR_INVALID;
+    if (desc->B <= 0 || desc->T <= 0 || desc->N <= 0) return PSVO_ERR_INVALID;
+    if (desc->two_q && (!mu2 || !sig_q2)) return PSVO_ERR_INVALID;
+    if (!desc->bootstrap && (!f || !sig_f)) return PSVO_ERR_INVALID;
+    if (desc->resample && !u && !idx_in) return PSVO_ERR_INVALID;
+    if (desc->N > 512) return PSVO_ERR_UNSUPPORTED;
+
+    FilterArgs a;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N;
+    a.resample = desc->resample; a.two_q = desc->two_q; a.bootstrap = desc->bootstrap;
+    a.q1 = *q1; a.f = desc->bootstrap ? *q1 : *f; a.g = *g;
+    a.sig_q1 = sig_q1; a.sig_q2 = sig_q2; a.sig_f = sig_f; a.sig_g = sig_g;
+    a.mu2 = mu2; a.m0 = m0; a.sig0 = sig0; a.fm0 = fm0; a.fsig0 = fsig0;
+    a.obs = obs; a.eps = eps; a.u = u; a.idx_in = idx_in;
+    a.X = X; a.Xanc = Xanc; a.Fm = Fm; a.logW = logW; a.idx_out = idx_out; a.lse = lse;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (desc->Dx) {
+        case 2: return dispatch_dy<2>(a, desc->Dy, desc->H, s);
+        case 3: return dispatch_dy<3>(a, desc->Dy, desc->H, s);
+        case 4: return dispatch_dy<4>(a, desc->Dy, desc->H, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}

@@ -1,0 +1,191 @@
+"""SSM -- mirror of reference src/model.py:10-192: which networks exist, their shapes, what is
+shared (f == q1 under use_bootstrap) and how sigma is wired (g_sigma_init = f_sigma_init quirk,
+model.py:37).  TF placeholders do not exist here: `obs` / `hidden` are fed as tensors.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .distribution.mvn import tf_mvn
+from .transformation.MLP import MLP_transformation
+
+
+class LSTMBlockCellLayer(nn.Module):
+    """One direction of tf.contrib.rnn.LSTMBlockCell (model.py:164-176) run over a sequence.
+
+    Parameters keep the TF layout: kernel (in + h, 4h) with gate order (i, j, f, o), bias (4h),
+    forget_bias = 1 added to f.  The sequence loop itself is upstream of the particle path
+    (SURVEY section 8f-1); it runs through torch's fused LSTM (MIOpen) after a layout permute.
+    """
+
+    def __init__(self, Din, Dh, name="lstm"):
+        super().__init__()
+        self.Din, self.Dh, self.name = Din, Dh, name
+        lim = math.sqrt(6.0 / (Din + Dh + 4 * Dh))          # glorot_uniform, TF default
+        self.kernel = nn.Parameter((torch.rand(Din + Dh, 4 * Dh) * 2 - 1) * lim)
+        self.bias = nn.Parameter(torch.zeros(4 * Dh))
+
+    def torch_weights(self):
+        Dh = self.Dh
+        i, j, f, o = self.kernel.split(Dh, dim=1)
+        w = torch.cat([i, f, j, o], dim=1)                  # torch gate order (i, f, g, o)
+        bi, bj, bf, bo = self.bias.split(Dh)
+        b = torch.cat([bi, bf + 1.0, bj, bo])
+        w_ih = w[:self.Din].t().contiguous()
+        w_hh = w[self.Din:].t().contiguous()
+        return w_ih, w_hh, b, torch.zeros_like(b)
+
+
+class StackBiRNN(nn.Module):
+    """tf.contrib.rnn.stack_bidirectional_dynamic_rnn over lists of LSTMBlockCells
+    (reference src/SMC/SVO.py:337-341): each layer consumes concat(fw, bw) of the previous."""
+
+    def __init__(self, Din, Dhs, name):
+        super().__init__()
+        self.fw, self.bw = nn.ModuleList(), nn.ModuleList()
+        d = Din
+        for i, Dh in enumerate(Dhs):
+            self.fw.append(LSTMBlockCellLayer(d, Dh, "{}_f_{}".format(name, i)))
+            self.bw.append(LSTMBlockCellLayer(d, Dh, "{}_b_{}".format(name, i)))
+            d = 2 * Dh
+        self.Dout = d
+
+    def forward(self, x_BTD):
+        h = x_BTD
+        B = h.shape[0]
+        for fw, bw in zip(self.fw, self.bw):
+            flat = list(fw.torch_weights()) + list(bw.torch_weights())
+            z = h.new_zeros(2, B, fw.Dh)
+            h, _, _ = torch._VF.lstm(h, (z, z), flat, True, 1, 0.0, self.training, True, True)
+        return h
+
+
+class SSM(nn.Module):
+    """state space model: keeps q, f, g and the obs smoothers (model.py:10-62)."""
+
+    def __init__(self, FLAGS):
+        super().__init__()
+        self.Dx, self.Dy = FLAGS.Dx, FLAGS.Dy
+        self.time, self.batch_size = FLAGS.time, FLAGS.batch_size
+
+        split = lambda s: [int(x) for x in str(s).split(",")]
+        self.q0_layers, self.q1_layers, self.q2_layers = split(FLAGS.q0_layers), split(FLAGS.q1_layers), split(FLAGS.q2_layers)
+        self.f_layers, self.g_layers = split(FLAGS.f_layers), split(FLAGS.g_layers)
+
+        self.q0_sigma_init, self.q0_sigma_min = FLAGS.q0_sigma_init, FLAGS.q0_sigma_min
+        self.q1_sigma_init, self.q1_sigma_min = FLAGS.q1_sigma_init, FLAGS.q1_sigma_min
+        self.q2_sigma_init, self.q2_sigma_min = FLAGS.q2_sigma_init, FLAGS.q2_sigma_min
+        self.f_sigma_init, self.f_sigma_min = FLAGS.f_sigma_init, FLAGS.f_sigma_min
+        self.g_sigma_init, self.g_sigma_min = FLAGS.f_sigma_init, FLAGS.g_sigma_min    # sic, model.py:37
+
+        self.y_smoother_Dhs = split(FLAGS.y_smoother_Dhs)
+        self.X0_smoother_Dhs = split(FLAGS.X0_smoother_Dhs)
+
+        self.output_cov, self.diag_cov = FLAGS.output_cov, FLAGS.diag_cov
+        self.use_bootstrap, self.use_2_q = FLAGS.use_bootstrap, FLAGS.use_2_q
+        self.poisson_emission = FLAGS.poisson_emission
+        self.X0_use_separate_RNN, self.use_stack_rnn = FLAGS.X0_use_separate_RNN, FLAGS.use_stack_rnn
+        self.PSVO, self.PSVOwR, self.SVO = FLAGS.PSVO, getattr(FLAGS, "PSVOwR", False), FLAGS.SVO
+        self.BSim_use_single_RNN = FLAGS.BSim_use_single_RNN
+
+        if self.poisson_emission:
+            raise NotImplementedError("poisson_emission is outside the MI355X hot-path scope (SURVEY section 2 row 2)")
+        if not self.use_stack_rnn:
+            raise NotImplementedError("use_stack_rnn=False (tf.nn.bidirectional_dynamic_rnn) is not built yet")
+
+        # placeholders of the reference (model.py:63-65) have no equivalent; kept as feed keys
+        self.obs, self.hidden = "obs", "hidden"
+
+        self.init_trans()
+        self.init_dist()
+        self.init_RNNs()
+
+    # feature widths of the proposal inputs (SVO.py:313-331,362-367)
+    def _feature_dims(self):
+        if self.SVO:
+            E = 2 * self.y_smoother_Dhs[-1]
+            Dh0 = self.X0_smoother_Dhs[-1] if self.X0_use_separate_RNN else self.y_smoother_Dhs[-1]
+            E0 = 4 * Dh0
+        else:
+            E = E0 = self.Dy
+        return E, E0
+
+    def init_trans(self):                                    # model.py:67-110
+        E, E0 = self._feature_dims()
+        both = self.use_bootstrap and self.use_2_q
+        q0_in = E0 if both else self.Dx                      # X0_transformer maps E0 -> Dx otherwise
+        mk = lambda layers, Dout, Din, name: MLP_transformation(layers, Dout, Din, output_cov=self.output_cov,
+                                                                diag_cov=self.diag_cov, name=name)
+        self.q0_tran = mk(self.q0_layers, self.Dx, q0_in, "q0_tran")
+        self.q1_tran = mk(self.q1_layers, self.Dx, self.Dx, "q1_tran")
+        self.q2_tran = mk(self.q2_layers, self.Dx, E, "q2_tran") if self.use_2_q else None
+        if self.PSVO or self.PSVOwR:
+            Eb = 2 * self.y_smoother_Dhs[-1]
+            self.BSim_q_init_tran = mk(self.q0_layers, self.Dx, Eb, "BSim_q_init_tran")
+            self.q1_inv_tran = mk(self.q1_layers, self.Dx, self.Dx, "q1_inv_tran")
+            self.BSim_q2_tran = mk(self.q2_layers, self.Dx, Eb, "BSim_q2_tran")
+        self.f_tran = self.q1_tran if self.use_bootstrap else mk(self.f_layers, self.Dx, self.Dx, "f_tran")
+        self.g_tran = mk(self.g_layers, self.Dy, self.Dx, "g_tran")
+
+    def init_dist(self):                                     # model.py:112-160
+        self.q0_dist = tf_mvn(self.q0_tran, self.q0_sigma_init, self.q0_sigma_min, "q0_dist")
+        self.q1_dist = tf_mvn(self.q1_tran, self.q1_sigma_init, self.q1_sigma_min, "q1_dist")
+        self.q2_dist = tf_mvn(self.q2_tran, self.q2_sigma_init, self.q2_sigma_min, "q2_dist") if self.use_2_q else None
+        if self.PSVO or self.PSVOwR:
+            self.Bsim_q_init_dist = tf_mvn(self.BSim_q_init_tran, self.q0_sigma_init, self.q0_sigma_min, "BSim_q_init_dist")
+            self.q1_inv_dist = tf_mvn(self.q1_inv_tran, self.q1_sigma_init, self.q1_sigma_min, "q1_inv_dist")
+            self.BSim_q2_dist = tf_mvn(self.BSim_q2_tran, self.q2_sigma_init, self.q2_sigma_min, "BSim_q2_dist")
+        if self.use_bootstrap:
+            self.f_dist = self.q1_dist
+        else:
+            self.f_dist = tf_mvn(self.f_tran, self.f_sigma_init, self.f_sigma_min, "f_dist")
+        self.g_dist = tf_mvn(self.g_tran, self.g_sigma_init, self.g_sigma_min, "g_dist")
+
+    def init_RNNs(self):                                     # model.py:162-192
+        if self.SVO or self.PSVO or self.PSVOwR:
+            self.y_smoother = StackBiRNN(self.Dy, self.y_smoother_Dhs, "y_smoother")
+            self.X0_smoother = (StackBiRNN(self.Dy, self.X0_smoother_Dhs, "X0_smoother")
+                                if self.X0_use_separate_RNN else None)
+            self.bRNN = (self.y_smoother, self.X0_smoother)
+        else:
+            self.y_smoother = self.X0_smoother = None
+            self.bRNN = None
+        if not (self.use_bootstrap and self.use_2_q):
+            _, E0 = self._feature_dims()
+            lim = math.sqrt(6.0 / E0)                        # Dense(Dx, he_uniform)
+            self.X0_transformer_kernel = nn.Parameter((torch.rand(E0, self.Dx) * 2 - 1) * lim)
+            self.X0_transformer_bias = nn.Parameter(torch.zeros(self.Dx))
+
+    def X0_transformer(self, x):
+        return x @ self.X0_transformer_kernel + self.X0_transformer_bias
+
+    # ------------------------------------------------------------------------------------------
+    def export_reference_layout(self, dtype=torch.float64):
+        """All variables in the reference's (keras / TF) layout, as plain CPU tensors.
+        Used to hand the same parameters to a checker or to a reference-format checkpoint."""
+        cv = lambda t: t.detach().to("cpu", dtype).clone()
+
+        def dist(d):
+            tr = d.transformation
+            return {"layers": [(cv(W), cv(b)) for W, b in zip(tr.kernels, tr.biases)],
+                    "mu": (cv(tr.mu_kernel), cv(tr.mu_bias)),
+                    "sigma_raw": cv(d.sigma_con), "sigma_min": float(d.sigma_min)}
+
+        P = {"q0": dist(self.q0_dist), "q1": dist(self.q1_dist), "g": dist(self.g_dist)}
+        if self.use_2_q:
+            P["q2"] = dist(self.q2_dist)
+        if not self.use_bootstrap:
+            P["f"] = dist(self.f_dist)
+        if not (self.use_bootstrap and self.use_2_q):
+            P["X0_transformer"] = (cv(self.X0_transformer_kernel), cv(self.X0_transformer_bias))
+        if self.bRNN is not None:
+            def stack(s):
+                return None if s is None else [{"fw": (cv(f.kernel), cv(f.bias)), "bw": (cv(b.kernel), cv(b.bias))}
+                                               for f, b in zip(s.fw, s.bw)]
+            P["bRNN"] = {"y_smoother": stack(self.y_smoother), "X0_smoother": stack(self.X0_smoother)}
+        if self.PSVO or self.PSVOwR:
+            P["BSim_q_init"] = dist(self.Bsim_q_init_dist)
+            P["q1_inv"] = dist(self.q1_inv_dist)
+            P["BSim_q2"] = dist(self.BSim_q2_dist)
+        return P

@@ -1,0 +1,139 @@
+"""Tensor-level wrappers over the C ABI: argument checking, output allocation, stream plumbing.
+
+All tensors use the library's particle-minor HBM layout (include/psvo_hip.h):
+particles (T, B, Dx, N), log-weights (T, B, N), features (T, B, D), bsim noise (T, B, Dx, N, M).
+PyTorch is only the allocator / stream provider here.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, shape, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError("%s must live in HBM (cuda tensor); got %s" % (name, t.device))
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+def _mlp_struct(p, Din, H, Dout, name):
+    """p = (W1 (Din,H), b1 (H), W2 (H,Dout), b2 (Dout)) keras-layout tensors."""
+    W1, b1, W2, b2 = p
+    _chk(W1, (Din, H), name + ".W1")
+    _chk(b1, (H,), name + ".b1")
+    _chk(W2, (H, Dout), name + ".W2")
+    _chk(b2, (Dout,), name + ".b2")
+    s = _lib.psvo_mlp()
+    s.W1, s.b1, s.W2, s.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
+    return s
+
+
+def make_desc(B, T, N, M, Dx, Dy, H, resample=True, two_q=True, bootstrap=True):
+    d = _lib.psvo_desc()
+    d.B, d.T, d.N, d.M, d.Dx, d.Dy, d.H = B, T, N, M, Dx, Dy, H
+    d.resample, d.two_q, d.bootstrap = int(resample), int(two_q), int(bootstrap)
+    return d
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
+                   obs, eps, u=None, idx_in=None):
+    """psvo_filter_forward.  Returns dict(X, Xanc, Fm, logW, idx, lse)."""
+    lib = _lib.load()
+    B, T, N, Dx, Dy, H = desc.B, desc.T, desc.N, desc.Dx, desc.Dy, desc.H
+    dev = eps.device
+    q1s = _mlp_struct(q1, Dx, H, Dx, "q1")
+    fs = None if desc.bootstrap else _mlp_struct(f, Dx, H, Dx, "f")
+    gs = _mlp_struct(g, Dx, H, Dy, "g")
+    _chk(sig_q1, (Dx,), "sig_q1"); _chk(sig_g, (Dy,), "sig_g")
+    if desc.two_q:
+        _chk(sig_q2, (Dx,), "sig_q2"); _chk(mu2, (T, B, Dx), "mu2")
+    if not desc.bootstrap:
+        _chk(sig_f, (Dx,), "sig_f")
+    _chk(m0, (B, Dx), "m0"); _chk(sig0, (Dx,), "sig0")
+    _chk(fm0, (B, Dx), "fm0"); _chk(fsig0, (Dx,), "fsig0")
+    _chk(obs, (T, B, Dy), "obs"); _chk(eps, (T, B, Dx, N), "eps")
+    _chk(u, (T, B, N), "u"); _chk(idx_in, (T, B, N), "idx_in", torch.int32)
+    if desc.resample and u is None and idx_in is None:
+        raise ValueError("resampling needs uniforms `u` or teacher-forced `idx_in`")
+    out = {
+        "X": torch.empty(T, B, Dx, N, device=dev), "Xanc": torch.empty(T, B, Dx, N, device=dev),
+        "Fm": torch.empty(T, B, Dx, N, device=dev), "logW": torch.empty(T, B, N, device=dev),
+        "idx": torch.empty(T, B, N, device=dev, dtype=torch.int32), "lse": torch.empty(T, B, device=dev),
+    }
+    st = lib.psvo_filter_forward(
+        ctypes.byref(desc), ctypes.byref(q1s), ctypes.byref(fs) if fs is not None else None, ctypes.byref(gs),
+        _ptr(sig_q1), _ptr(sig_q2), _ptr(sig_f), _ptr(sig_g), _ptr(mu2), _ptr(m0), _ptr(sig0), _ptr(fm0),
+        _ptr(fsig0), _ptr(obs), _ptr(eps), _ptr(u), _ptr(idx_in),
+        _ptr(out["X"]), _ptr(out["Xanc"]), _ptr(out["Fm"]), _ptr(out["logW"]), _ptr(out["idx"]), _ptr(out["lse"]),
+        _stream())
+    _lib.check(st, "psvo_filter_forward")
+    return out
+
+
+def bsim_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
+                 imean, isig, obs, eps_b, u_b=None, sel_in=None):
+    """psvo_bsim_forward.  `filt` is the dict returned by filter_forward.
+    Returns dict(bwX, flp, glp, Omega, sel, score)."""
+    lib = _lib.load()
+    B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
+    dev = eps_b.device
+    fs = _mlp_struct(f, Dx, H, Dx, "f")
+    gs = _mlp_struct(g, Dx, H, Dy, "g")
+    qs = _mlp_struct(q1_inv, Dx, H, Dx, "q1_inv")
+    for k in ("X", "Fm"):
+        _chk(filt[k], (T, B, Dx, N), k)
+    _chk(filt["logW"], (T, B, N), "logW"); _chk(filt["lse"], (T, B), "lse")
+    _chk(sig_f, (Dx,), "sig_f"); _chk(sig_g, (Dy,), "sig_g")
+    _chk(sig_q1inv, (Dx,), "sig_q1inv"); _chk(sig_bq2, (Dx,), "sig_bq2")
+    _chk(bmu2, (T, B, Dx), "bmu2"); _chk(minit, (B, Dx), "minit"); _chk(sig_init, (Dx,), "sig_init")
+    _chk(imean, (B, Dx), "imean"); _chk(isig, (Dx,), "isig")
+    _chk(obs, (T, B, Dy), "obs"); _chk(eps_b, (T, B, Dx, N, M), "eps_b")
+    _chk(u_b, (T, B, N), "u_b"); _chk(sel_in, (T, B, N), "sel_in", torch.int32)
+    if u_b is None and sel_in is None:
+        raise ValueError("backward simulation needs uniforms `u_b` or teacher-forced `sel_in`")
+    out = {
+        "bwX": torch.empty(T, B, Dx, N, device=dev), "flp": torch.empty(T, B, N, device=dev),
+        "glp": torch.empty(T, B, N, device=dev), "Omega": torch.empty(T, B, N, device=dev),
+        "sel": torch.empty(T, B, N, device=dev, dtype=torch.int32), "score": torch.empty(B, N, device=dev),
+    }
+    st = lib.psvo_bsim_forward(
+        ctypes.byref(desc), _ptr(filt["X"]), _ptr(filt["Fm"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
+        ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs),
+        _ptr(sig_f), _ptr(sig_g), _ptr(sig_q1inv), _ptr(sig_bq2), _ptr(bmu2), _ptr(minit), _ptr(sig_init),
+        _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(u_b), _ptr(sel_in),
+        _ptr(out["bwX"]), _ptr(out["flp"]), _ptr(out["glp"]), _ptr(out["Omega"]), _ptr(out["sel"]),
+        _ptr(out["score"]), _stream())
+    _lib.check(st, "psvo_bsim_forward")
+    return out
+
+
+def elbo_filter(desc, lse):
+    lib = _lib.load()
+    _chk(lse, (desc.T, desc.B), "lse")
+    out = torch.empty(desc.B, device=lse.device)
+    _lib.check(lib.psvo_elbo_filter(ctypes.byref(desc), _ptr(lse), _ptr(out), _stream()), "psvo_elbo_filter")
+    return out
+
+
+def elbo_bsim(desc, score):
+    lib = _lib.load()
+    _chk(score, (desc.B, desc.N), "score")
+    out = torch.empty(desc.B, device=score.device)
+    _lib.check(lib.psvo_elbo_bsim(ctypes.byref(desc), _ptr(score), _ptr(out), _stream()), "psvo_elbo_bsim")
+    return out

@@ -1,0 +1,67 @@
+"""MLP_transformation -- mirror of reference src/transformation/MLP.py:8-86 (output_cov=False).
+
+Weights keep the keras Dense layout (kernel (in, out), y = x @ kernel + bias) so they can be
+handed to the HIP kernels (psvo_mlp in include/psvo_hip.h) without a transpose.
+"""
+import math
+
+import torch
+from torch import nn
+
+
+def _he_normal_(w):
+    """keras he_normal: truncated normal, stddev sqrt(2 / fan_in) (MLP.py:29-38)."""
+    fan_in = w.shape[0]
+    std = math.sqrt(2.0 / fan_in) / 0.87962566103423978
+    with torch.no_grad():
+        nn.init.trunc_normal_(w, mean=0.0, std=std, a=-2 * std, b=2 * std)
+    return w
+
+
+class MLP_transformation(nn.Module):
+    def __init__(self, Dhs, Dout, Din, use_residual=False, output_cov=False, diag_cov=False,
+                 name="MLP_transformation"):
+        super().__init__()
+        if output_cov:
+            # reference MLP.py:40-46,60-66: state-dependent covariance head -- not on the BASELINE path
+            raise NotImplementedError("output_cov=True is outside the MI355X hot-path scope (SURVEY section 8f-4)")
+        self.Dhs, self.Dout, self.Din = list(Dhs), Dout, Din
+        self.use_residual = use_residual
+        self.output_cov, self.diag_cov = output_cov, diag_cov
+        self.name = name
+        self.kernels = nn.ParameterList()
+        self.biases = nn.ParameterList()
+        d = Din
+        for Dh in self.Dhs:                                # hidden_{i}: Dense(relu, he_normal)
+            self.kernels.append(nn.Parameter(_he_normal_(torch.empty(d, Dh))))
+            self.biases.append(nn.Parameter(torch.zeros(Dh)))
+            d = Dh
+        self.mu_kernel = nn.Parameter(_he_normal_(torch.empty(d, Dout)))   # mu_layer: Dense(linear)
+        self.mu_bias = nn.Parameter(torch.zeros(Dout))
+
+    def transform(self, Input):
+        """reference MLP.py:48-68; returns (mu, None)."""
+        hidden = Input
+        for W, b in zip(self.kernels, self.biases):
+            hidden = torch.relu(hidden @ W + b)
+        mu = hidden @ self.mu_kernel + self.mu_bias
+        if self.use_residual:
+            mu = mu + Input
+        return mu, None
+
+    def hip_params(self):
+        """(W1, b1, W2, b2) for the fused kernels: exactly one hidden layer."""
+        if len(self.Dhs) != 1:
+            raise ValueError("%s: the fused HIP kernels take one hidden layer per particle MLP, got %s "
+                             "(no fallback path exists)" % (self.name, self.Dhs))
+        return (self.kernels[0], self.biases[0], self.mu_kernel, self.mu_bias)
+
+    def get_variables(self):
+        """reference MLP.py:70-86."""
+        res = {}
+        for i, (W, b) in enumerate(zip(self.kernels, self.biases)):
+            res["hidden_{}/weights".format(i)] = W
+            res["hidden_{}/bias".format(i)] = b
+        res["mu_layer/weights"] = self.mu_kernel
+        res["mu_layer/bias"] = self.mu_bias
+        return res

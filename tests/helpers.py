@@ -1,0 +1,70 @@
+"""Test-side glue between the oracle (reference layout (T, N, B, D), fp64) and the product
+(HBM layout (T, B, D, N), fp32).  Only tests import this."""
+import torch
+
+from oracle import psvo_oracle as O
+from psvo_amd.flags import Flags
+
+
+def make_flags(objective, **kw):
+    base = dict(PSVO=False, SVO=False, AESMC=False, IWAE=False, PSVOwR=False)
+    base[objective] = True
+    base.update(kw)
+    return Flags(**base)
+
+
+def oracle_flags(FLAGS, objective):
+    return dict(Dx=FLAGS.Dx, Dy=FLAGS.Dy, n_particles=FLAGS.n_particles,
+                n_particles_for_BSim_proposal=FLAGS.n_particles_for_BSim_proposal,
+                use_bootstrap=FLAGS.use_bootstrap, use_2_q=FLAGS.use_2_q, objective=objective)
+
+
+def noise_to_hip(noise, device):
+    out = {}
+    f32 = lambda t: t.to(torch.float32).contiguous().to(device)
+    if "eps_f" in noise:
+        out["eps_f"] = f32(noise["eps_f"].permute(0, 2, 3, 1))
+    if "u_f" in noise:
+        out["u_f"] = f32(noise["u_f"].permute(0, 2, 1))
+    if noise.get("idx_f") is not None:
+        out["idx_f"] = noise["idx_f"].permute(0, 2, 1).to(torch.int32).contiguous().to(device)
+    if "eps_b" in noise:
+        out["eps_b"] = f32(noise["eps_b"].permute(0, 3, 4, 2, 1))
+    if "u_b" in noise:
+        out["u_b"] = f32(noise["u_b"].permute(0, 2, 1))
+    if noise.get("idx_b") is not None:
+        out["sel_b"] = noise["idx_b"].permute(0, 2, 1).to(torch.int32).contiguous().to(device)
+    return out
+
+
+def part_to_ref(t):
+    """(T, B, Dx, N) -> (T, N, B, Dx)"""
+    return t.permute(0, 3, 1, 2).double().cpu()
+
+
+def w_to_ref(t):
+    """(T, B, N) -> (T, N, B)"""
+    return t.permute(0, 2, 1).double().cpu()
+
+
+def perturb_(model, seed=7, scale=0.3):
+    """Give biases and sigmas non-trivial values so that every term of the arithmetic is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("bias") or "biases" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * scale)
+            if name.endswith("sigma_con"):
+                p.copy_(0.5 + 1.5 * torch.rand(p.shape, generator=g))
+    return model
+
+
+def run_oracle(model, FLAGS, objective, obs, noise, teacher=None):
+    P = model.export_reference_layout(torch.float64)
+    o = O.OBJECTIVES[objective](P, oracle_flags(FLAGS, objective))
+    nz = dict(noise)
+    if teacher:
+        nz.update(teacher)
+    with torch.no_grad():
+        z, log = o.get_log_ZSMC(obs.double().cpu(), nz)
+    return z, log

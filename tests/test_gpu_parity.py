@@ -1,0 +1,105 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on identical inputs + noise.
+
+Tolerances (fp32 kernels vs fp64 oracle), stated per quantity:
+  particles / trajectories   atol 2e-4 (values O(1..10))
+  log-weights, log-densities atol 5e-4
+  ELBO                       rel  1e-4  (north-star bar is 1e-3)
+Teacher-forced runs inject the oracle's ancestor / sub-particle indices, so every downstream
+quantity is comparable; free-running runs check that the in-kernel multinomial draw reproduces
+the oracle's indices (up to draws whose uniform lies within rounding of a CDF edge).
+"""
+import pytest
+import torch
+
+from oracle import psvo_oracle as O
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # objective, B, T, N, M, Dx, Dy, H, bootstrap, two_q
+    ("AESMC", 2, 6, 8, 4, 2, 1, 16, True, True),
+    ("AESMC", 3, 9, 64, 4, 2, 1, 32, True, True),
+    ("AESMC", 2, 7, 100, 4, 3, 2, 32, False, True),
+    ("AESMC", 2, 7, 130, 4, 2, 1, 32, True, False),
+    ("AESMC", 2, 5, 300, 4, 4, 1, 64, False, False),
+    ("IWAE", 1, 50, 4, 4, 2, 1, 32, True, True),
+    ("IWAE", 2, 8, 96, 4, 3, 1, 16, False, True),
+    ("SVO", 2, 8, 32, 4, 2, 1, 32, True, True),
+    ("SVO", 2, 6, 16, 4, 3, 1, 32, False, False),
+    ("PSVO", 2, 6, 8, 4, 2, 1, 16, True, True),
+    ("PSVO", 2, 7, 64, 16, 2, 1, 32, True, True),
+    ("PSVO", 2, 6, 50, 8, 3, 1, 32, True, True),
+    ("PSVO", 1, 5, 36, 32, 4, 2, 32, False, True),
+    ("PSVO", 2, 5, 130, 16, 2, 1, 64, True, False),
+    ("PSVO", 1, 5, 20, 4, 3, 1, 32, False, False),
+]
+
+
+def _setup(obj, B, T, N, M, Dx, Dy, H, bootstrap, two_q, seed=0):
+    from psvo_amd.model import SSM
+    from psvo_amd.SMC.SVO import SVO
+    from psvo_amd.SMC.PSVO import PSVO
+    from psvo_amd.SMC.AESMC import AESMC
+    from psvo_amd.SMC.IWAE import IWAE
+    cls = {"SVO": SVO, "PSVO": PSVO, "AESMC": AESMC, "IWAE": IWAE}[obj]
+    hs = str(H)
+    FLAGS = Hh.make_flags(obj, Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, batch_size=B, time=T,
+                          q0_layers=hs, q1_layers=hs, q2_layers=hs, f_layers=hs, g_layers=hs,
+                          y_smoother_Dhs="8", X0_smoother_Dhs="8", use_bootstrap=bootstrap, use_2_q=two_q)
+    torch.manual_seed(seed)
+    model = Hh.perturb_(SSM(FLAGS)).cuda()
+    smc = cls(model, FLAGS)
+    g = torch.Generator().manual_seed(100 + seed)
+    obs = torch.randn(B, T, Dy, generator=g, dtype=torch.float64) * 1.5
+    noise = O.make_noise(Hh.oracle_flags(FLAGS, obj), B, T, seed=1234 + seed)
+    return FLAGS, model, smc, obs, noise
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(map(str, c)))
+def test_teacher_forced_parity(built_lib, case):
+    obj = case[0]
+    FLAGS, model, smc, obs, noise = _setup(*case)
+    z_ref, ref = Hh.run_oracle(model, FLAGS, obj, obs, noise)
+    teacher = {"idx_f": ref["idx_f"]} if ref["idx_f"] is not None else {}
+    if obj == "PSVO":
+        teacher["idx_b"] = ref["idx_b"]
+    nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
+    nz.pop("u_f", None) if "idx_f" in nz else None
+    nz.pop("u_b", None) if "sel_b" in nz else None
+    with torch.no_grad():
+        z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
+    torch.cuda.synchronize()
+    filt = log["filter"]
+    assert torch.allclose(Hh.part_to_ref(filt["X"]), ref["X_prevs"], atol=2e-4, rtol=1e-5)
+    assert torch.allclose(Hh.part_to_ref(filt["Xanc"]), ref["X_ancestors"], atol=2e-4, rtol=1e-5)
+    assert torch.allclose(Hh.w_to_ref(filt["logW"]), ref["log_Ws"], atol=5e-4, rtol=1e-5)
+    assert torch.allclose(filt["lse"].double().cpu(), torch.logsumexp(ref["log_Ws"], 1), atol=5e-4, rtol=1e-5)
+    if obj == "PSVO":
+        bs = log["bsim"]
+        assert torch.allclose(Hh.part_to_ref(bs["bwX"]), ref["bw_Xs"], atol=2e-4, rtol=1e-5)
+        assert torch.allclose(Hh.w_to_ref(bs["flp"]), ref["f_log_probs"], atol=5e-4, rtol=1e-5)
+        assert torch.allclose(Hh.w_to_ref(bs["glp"]), ref["g_log_probs"], atol=5e-4, rtol=1e-5)
+        assert torch.allclose(Hh.w_to_ref(bs["Omega"]), ref["bw_log_Omegas"], atol=5e-4, rtol=1e-5)
+    assert torch.allclose(log["Xs"].double().cpu(), ref["Xs"], atol=2e-4, rtol=1e-5)
+    assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(map(str, c)))
+def test_free_running_indices(built_lib, case):
+    """In-kernel multinomial draws (prefix-sum CDF + search) against the oracle's definition."""
+    obj = case[0]
+    FLAGS, model, smc, obs, noise = _setup(*case, seed=3)
+    z_ref, ref = Hh.run_oracle(model, FLAGS, obj, obs, noise)
+    nz = Hh.noise_to_hip(noise, "cuda")
+    with torch.no_grad():
+        z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
+    torch.cuda.synchronize()
+    if ref["idx_f"] is not None:
+        idx = log["filter"]["idx"].permute(0, 2, 1).cpu().long()
+        assert (idx != ref["idx_f"]).float().mean() == 0.0
+    if obj == "PSVO":
+        sel = log["bsim"]["sel"].permute(0, 2, 1).cpu().long()
+        assert (sel != ref["idx_b"]).float().mean() == 0.0
+    assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+    assert torch.allclose(log["Xs"].double().cpu(), ref["Xs"], atol=2e-4, rtol=1e-5)
