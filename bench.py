@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the PSVO hot path on MI355X (driver contract: see README/DESIGN).
+
+A "step" is one full evaluation of the objective on one batch of synthetic Fitzhugh-Nagumo
+sequences that is already resident in HBM: observation encoder, hoisted proposal means, random
+draws, forward particle filter, backward simulation (the N x N term) and the ELBO reduction.
+Workload = BASELINE.json's target configuration "C*": PSVO (the reference's backward-simulation
+objective, BASELINE "SVO"), batch=32 per GPU, T=200, N=128, Dx=2, M=16, H=32, Dh=32.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; the batch of
+sequences is sharded (32 per rank, weak scaling), there is no data-path collective in a forward
+evaluation, and the timed region is bracketed by barrier + synchronize with MAX over ranks.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: objective, B per GPU, T, N, Dx, Dy, M, H, Dh
+    "C*": ("PSVO", 32, 200, 128, 2, 1, 16, 32, 32),
+    "C2": ("AESMC", 16, 200, 64, 2, 1, 16, 32, 32),
+    "C3": ("PSVO", 32, 400, 128, 3, 1, 16, 32, 32),
+    "C4": ("PSVO", 32, 200, 256, 2, 1, 16, 32, 32),
+    "C5": ("PSVO", 8, 1000, 512, 4, 1, 16, 32, 32),
+}
+FP32_PEAK_TFLOPS = 157.3     # MI355X f32 vector peak == f32-input MFMA dense peak (MI355X_MICROARCH.md)
+EXP_PEAK = 9.8e12            # transcendental quarter rate, exp/s
+
+
+def flop_model(Dx, Dy, N, M, H, E):
+    """Algorithmic flop per particle-step, SURVEY.md section 8(d)."""
+    mlp = lambda i, o: 2 * H * (i + o)
+    f_filt = mlp(Dx, Dx) + mlp(Dx, Dy) + mlp(E, Dx) / N + 20 * Dx + 6 * Dy + 10
+    f_bsim = 2 * mlp(Dx, Dx) + M * (mlp(Dx, Dx) + mlp(Dx, Dy)) + M * N * (3 * Dx + 4) + M * (14 * Dx + 6 * Dy + 12)
+    return f_filt, f_bsim, M * N
+
+
+def fhn_batch(B, T, seed, device):
+    """Synthetic FHN observations: RK4 restatement of the reference generator
+    (src/transformation/fhn.py:26-35, src/utils/data_generator.py:38-45): (a,b,c,I,dt) =
+    (1.0, 0.95, 0.05, 1.0, 0.15), x0 ~ U(-2.5, 2.5)^2, y = N(x_1, 0.01)."""
+    g = torch.Generator().manual_seed(seed)
+    a, b, c, I, dt = 1.0, 0.95, 0.05, 1.0, 0.15
+    x = torch.rand(B, 2, generator=g, dtype=torch.float64) * 5.0 - 2.5
+
+    def rhs(x):
+        V, w = x[:, 0], x[:, 1]
+        return torch.stack([V - V ** 3 / 3 - w + I, a * (b * V - c * w)], 1)
+    xs, h = [x], dt / 4
+    for _ in range(T - 1):
+        for _ in range(4):
+            k1 = rhs(x); k2 = rhs(x + 0.5 * h * k1); k3 = rhs(x + 0.5 * h * k2); k4 = rhs(x + h * k3)
+            x = x + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+        xs.append(x)
+    hidden = torch.stack(xs, 1)
+    obs = hidden[:, :, :1] + 0.1 * torch.randn(B, T, 1, generator=g, dtype=torch.float64)
+    return hidden.float().to(device), obs.float().to(device)
+
+
+def build_objective(wl, device, seed=0):
+    from psvo_amd.flags import Flags
+    from psvo_amd.model import SSM
+    from psvo_amd.SMC.AESMC import AESMC
+    from psvo_amd.SMC.IWAE import IWAE
+    from psvo_amd.SMC.PSVO import PSVO
+    from psvo_amd.SMC.SVO import SVO
+    obj, B, T, N, Dx, Dy, M, H, Dh = wl
+    flags = dict(PSVO=False, SVO=False, AESMC=False, IWAE=False)
+    flags[obj] = True
+    hs = str(H)
+    FLAGS = Flags(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, batch_size=B, time=T,
+                  q0_layers=hs, q1_layers=hs, q2_layers=hs, f_layers=hs, g_layers=hs,
+                  y_smoother_Dhs=str(Dh), X0_smoother_Dhs=str(Dh), **flags)
+    torch.manual_seed(seed)
+    model = SSM(FLAGS).to(device)
+    smc = {"PSVO": PSVO, "SVO": SVO, "AESMC": AESMC, "IWAE": IWAE}[obj](model, FLAGS)
+    return FLAGS, model, smc
+
+
+def cpu_baseline(wl, model, obs_cpu, sample_T, threads):
+    """Time the CPU oracle (op-for-op restatement of the reference's TF graph, including the
+    materialised (M, N, N, B) tile) on the host cores, on the first `sample_T` time steps."""
+    from oracle import psvo_oracle as O
+    obj, B, T, N, Dx, Dy, M, H, Dh = wl
+    torch.set_num_threads(threads)
+    P = O.params_to(model.export_reference_layout(torch.float32), torch.float32)
+    fl = dict(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, use_bootstrap=True, use_2_q=True,
+              objective=obj)
+    o = O.OBJECTIVES[obj](P, fl)
+    obs_s = obs_cpu[:, :sample_T].contiguous()
+    noise = O.make_noise(fl, B, sample_T, seed=99, dtype=torch.float32)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        o.get_log_ZSMC(obs_s, noise)
+        dt = time.perf_counter() - t0
+    return {"value": B * sample_T * N / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "sample": "forward evaluation (no_grad, fp32) of the first %d of %d time steps of the same workload, "
+                      "PyTorch-CPU oracle, %.1f s" % (sample_T, T, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C*", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-T", type=int, default=200)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the PSVO hot path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    wl = WORKLOADS[args.workload]
+    obj, B, T, N, Dx, Dy, M, H, Dh = wl
+    FLAGS, model, smc = build_objective(wl, device, seed=0)
+    smc.generator = torch.Generator(device=device).manual_seed(1234 + rank)
+    hidden, obs = fhn_batch(B, T, seed=100 + rank, device=device)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    kern = {"i": -1}
+    dominant = "psvo_bsim_forward" if obj == "PSVO" else "psvo_filter_forward"
+
+    # HIP events around the dominant kernel, on the stream it is launched on (torch's current stream)
+    from psvo_amd import ops
+    target = ops.bsim_forward if obj == "PSVO" else ops.filter_forward
+    name = target.__name__
+
+    def timed(*a, **k):
+        i = kern["i"]
+        if i >= 0:
+            ev[i][0].record()
+        out = target(*a, **k)
+        if i >= 0:
+            ev[i][1].record()
+        return out
+    setattr(ops, name, timed)
+
+    def step():
+        with torch.no_grad():
+            z, log = smc.get_log_ZSMC(obs, hidden)
+        return z
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        z = step()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        kern["i"] = i
+        z = step()
+    kern["i"] = -1
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    elbo = float(z)
+
+    if rank == 0:
+        k_ms = sorted(a.elapsed_time(b) for a, b in ev)
+        k_avg = sum(k_ms) / len(k_ms)
+        E = Dy
+        f_filt, f_bsim, x_bsim = flop_model(Dx, Dy, N, M, H, E)
+        f_dom = f_bsim if obj == "PSVO" else f_filt
+        units = B * T * N                                    # particle-steps one launch processes
+        achieved = units * f_dom / (k_avg * 1e-3) / 1e12
+        value = world * units * args.steps / elapsed
+        out = {
+            "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s on Fitzhugh-Nagumo, batch=%d/GPU, T=%d, N=%d, Dx=%d, M=%d, H=%d, Dh=%d"
+                                   % (args.workload, obj, B, T, N, Dx, M, H, Dh),
+                       "mode": "objective evaluation (ELBO + smoothed trajectories), forward only",
+                       "global_batch": B * world, "parallelism": "dp%d (batch of sequences sharded)" % world,
+                       "elbo": elbo},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "kernel": dominant, "kernel_ms_avg": k_avg, "kernel_ms_median": k_ms[len(k_ms) // 2],
+                         "flop_per_particle_step": f_dom,
+                         "exp_frac": (units * x_bsim / (k_avg * 1e-3) / EXP_PEAK) if obj == "PSVO" else None,
+                         "note": "fp32 VALU + transcendental work, not GEMM-shaped: priced against the f32 peak "
+                                 "(f32-input MFMA dense peak == f32 vector peak = 157.3 TFLOP/s); the path is "
+                                 "serial in t, so it is latency-limited well before this ceiling"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, model.cpu(), obs.cpu(), min(args.cpu_sample_T, T),
+                                               min(args.cpu_threads, os.cpu_count() or 1))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,8 @@ typedef struct {
 
 int psvo_abi_version(void);
 const char* psvo_status_string(int status);
+/* hipGetErrorString of the most recent failed launch on the calling thread (PSVO_ERR_HIP). */
+const char* psvo_last_hip_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Forward particle filter.  Replaces SVO.SMC (reference src/SMC/SVO.py:60-180) including
@@ -135,6 +137,19 @@ int psvo_bsim_forward(const psvo_desc* desc,
                       const float* obs, const float* eps_b, const float* u_b, const int32_t* sel_in,
                       float* bwX, float* flp, float* glp, float* Omega, int32_t* sel_out,
                       float* score, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One bidirectional LSTMBlockCell layer over a batch of sequences -- the observation encoder
+ * upstream of the particle path.  Replaces one layer of stack_bidirectional_dynamic_rnn over
+ * tf.contrib.rnn.LSTMBlockCell (reference src/SMC/SVO.py:337-341, src/model.py:164-176).
+ *   x (B,T,Din); W_fw / W_bw (Din+Dh, 4Dh) TF kernels, gate order (i, j, f, o); b_* (4Dh);
+ *   forget_bias = 1.  out (B,T,2Dh) = concat(forward h, backward h).
+ *   cs (2,B,T,Dh) cell states and gates (2,B,T,4Dh) activated gates are optional (NULL) saves
+ *   for back-propagation through time.  Dh in {8,16,32,64}, Din <= 128.
+ * ------------------------------------------------------------------------------------------- */
+int psvo_bilstm_forward(int B, int T, int Din, int Dh, const float* x,
+                        const float* W_fw, const float* b_fw, const float* W_bw, const float* b_bw,
+                        float* out, float* cs, float* gates, void* stream);
 
 /* Per-sequence ELBO reductions (no batch mean: the caller averages, so a batch shard can be
  * all-reduced).  filter: out[b] = sum_t lse[t,b] (SVO.compute_log_ZSMC, SVO.py:302-311);

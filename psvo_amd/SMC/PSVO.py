@@ -73,4 +73,5 @@ class PSVO(SVO):
         """PSVO.py:205-216."""
         if self.BSim_use_single_RNN:
             raise NotImplementedError("BSim_use_single_RNN (unidirectional static_rnn) is not built yet")
-        return self.preprocess_obs_w_bRNN(obs)
+        # the X0 feature of this encoder pass is never read (PSVO.py:80): do not compute it
+        return self.preprocess_obs_w_bRNN(obs, need_X0=False)

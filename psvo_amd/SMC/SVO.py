@@ -126,12 +126,15 @@ class SVO:
             preprocessed_X0 = self.model.X0_transformer(preprocessed_X0)
         return preprocessed_X0, preprocessed_obs
 
-    def preprocess_obs_w_bRNN(self, obs):
+    def preprocess_obs_w_bRNN(self, obs, need_X0=True):
         """SVO.py:333-369 (use_stack_rnn): bi-LSTM encodings (B, T, 2Dh) and the X0 feature
-        concat(out[:, -1], out[:, 0]) (B, 4Dh)."""
+        concat(out[:, -1], out[:, 0]) (B, 4Dh).  `need_X0=False` skips the separate X0 encoder
+        when the caller discards its output (PSVO.BS_preprocess_obs, reference PSVO.py:80)."""
         y_smoother, X0_smoother = self.model.bRNN
         outputs = y_smoother(obs)
         preprocessed_obs = outputs
+        if not need_X0:
+            return None, preprocessed_obs
         if self.X0_use_separate_RNN:
             outputs = X0_smoother(obs)
         preprocessed_X0 = torch.cat([outputs[:, -1], outputs[:, 0]], dim=-1)

@@ -36,8 +36,10 @@ _MLP = ctypes.POINTER(psvo_mlp)
 SIGNATURES = {
     "psvo_abi_version": (ctypes.c_int, []),
     "psvo_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "psvo_last_hip_error": (ctypes.c_char_p, []),
     "psvo_filter_forward": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 19 + [_P]),
     "psvo_bsim_forward": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 19 + [_P]),
+    "psvo_bilstm_forward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 8 + [_P]),
     "psvo_elbo_filter": (ctypes.c_int, [_DESC, _P, _P, _P]),
     "psvo_elbo_bsim": (ctypes.c_int, [_DESC, _P, _P, _P]),
 }
@@ -53,6 +55,9 @@ def load():
             raise PsvoHipError(
                 "libpsvo_hip.so not found at %s -- build it with `python -m psvo_amd.build` "
                 "(there is no CPU or PyTorch fallback for the PSVO hot path)" % LIB_PATH)
+        # torch owns the device memory and the streams handed to the library, so both must share
+        # ONE HIP runtime: import torch first so that its libamdhip64 is the one the loader binds.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
@@ -65,5 +70,7 @@ def load():
 def check(status, what):
     if status != PSVO_OK:
         msg = load().psvo_status_string(status).decode()
+        if status == PSVO_ERR_HIP:
+            msg += ": " + load().psvo_last_hip_error().decode()
         exc = ValueError if status in (PSVO_ERR_INVALID, PSVO_ERR_UNSUPPORTED) else PsvoHipError
         raise exc("%s failed: %s (status %d)" % (what, msg, status))

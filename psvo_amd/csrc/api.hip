@@ -27,7 +27,13 @@ __global__ void elbo_bsim_kernel(const float* __restrict__ score, float* __restr
 
 }  // namespace psvo
 
+namespace psvo {
+thread_local hipError_t g_last_hip_error = hipSuccess;
+}
+
 extern "C" int psvo_abi_version(void) { return PSVO_ABI_VERSION; }
+
+extern "C" const char* psvo_last_hip_error(void) { return hipGetErrorString(psvo::g_last_hip_error); }
 
 extern "C" const char* psvo_status_string(int status) {
     switch (status) {
@@ -41,14 +47,16 @@ extern "C" const char* psvo_status_string(int status) {
 
 extern "C" int psvo_elbo_filter(const psvo_desc* desc, const float* lse, float* out, void* stream) {
     if (!desc || !lse || !out || desc->B <= 0 || desc->T <= 0) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
     hipLaunchKernelGGL(psvo::elbo_filter_kernel, dim3(desc->B), dim3(64), 0, static_cast<hipStream_t>(stream), lse,
                        out, desc->T, desc->B);
-    return hipGetLastError() == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
+    return psvo::launch_status();
 }
 
 extern "C" int psvo_elbo_bsim(const psvo_desc* desc, const float* score, float* out, void* stream) {
     if (!desc || !score || !out || desc->B <= 0 || desc->N <= 0) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
     hipLaunchKernelGGL(psvo::elbo_bsim_kernel, dim3(desc->B), dim3(64), 0, static_cast<hipStream_t>(stream), score,
                        out, desc->N);
-    return hipGetLastError() == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
+    return psvo::launch_status();
 }

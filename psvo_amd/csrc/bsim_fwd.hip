@@ -409,8 +409,9 @@ static int launch_bsim(const BsimArgs& a, hipStream_t stream) {
     const int cpb = NTB / M;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS);
     dim3 grid((a.N + cpb - 1) / cpb, a.B);
+    clear_hip_error();
     hipLaunchKernelGGL((bsim_fwd_kernel<DX, DY, H, M>), grid, dim3(NTB), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
+    return launch_status();
 }
 
 template <int DX, int DY, int H>

@@ -12,6 +12,16 @@ constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kHalfLog2Pi = 0.9189385332046727f;
 constexpr int kWave = 64;
 
+// Launch-status helper.  hipGetLastError() is sticky across *any* earlier HIP call of the process
+// (torch's own probing calls included), so clear it before the launch and read it after.
+extern thread_local hipError_t g_last_hip_error;
+inline void clear_hip_error() { (void)hipGetLastError(); }
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) g_last_hip_error = e;
+    return e == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
+}
+
 // v_exp_f32 / v_log_f32 are base-2 on CDNA; keep hot loops in the log2 domain.
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }

@@ -281,13 +281,14 @@ static int launch_filter(const FilterArgs& a, hipStream_t stream) {
     using MG = MlpLds<DX, H, DY>;
     const int NT = (a.N + 63) & ~63;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + NT + 3 * DX * NT + 48);
+    clear_hip_error();
     // the register budget follows the workgroup size: <= 256 threads is one wave per SIMD, so
     // the compiler may keep every MLP weight resident in VGPRs
     if (NT <= 256)
         hipLaunchKernelGGL((filter_fwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, a);
     else
         hipLaunchKernelGGL((filter_fwd_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
+    return launch_status();
 }
 
 template <int DX, int DY>

@@ -137,3 +137,21 @@ def elbo_bsim(desc, score):
     out = torch.empty(desc.B, device=score.device)
     _lib.check(lib.psvo_elbo_bsim(ctypes.byref(desc), _ptr(score), _ptr(out), _stream()), "psvo_elbo_bsim")
     return out
+
+
+def bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=False):
+    """psvo_bilstm_forward: x (B,T,Din) -> out (B,T,2Dh) [, cs (2,B,T,Dh), gates (2,B,T,4Dh)]."""
+    lib = _lib.load()
+    B, T, Din = x.shape
+    Dh = W_fw.shape[1] // 4
+    _chk(x, (B, T, Din), "x")
+    for nm, W, b in (("fw", W_fw, b_fw), ("bw", W_bw, b_bw)):
+        _chk(W, (Din + Dh, 4 * Dh), "W_" + nm)
+        _chk(b, (4 * Dh,), "b_" + nm)
+    out = torch.empty(B, T, 2 * Dh, device=x.device)
+    cs = torch.empty(2, B, T, Dh, device=x.device) if save else None
+    gates = torch.empty(2, B, T, 4 * Dh, device=x.device) if save else None
+    st = lib.psvo_bilstm_forward(B, T, Din, Dh, _ptr(x), _ptr(W_fw), _ptr(b_fw), _ptr(W_bw), _ptr(b_bw),
+                                 _ptr(out), _ptr(cs), _ptr(gates), _stream())
+    _lib.check(st, "psvo_bilstm_forward")
+    return (out, cs, gates) if save else out

@@ -103,3 +103,19 @@ def test_free_running_indices(built_lib, case):
         assert (sel != ref["idx_b"]).float().mean() == 0.0
     assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
     assert torch.allclose(log["Xs"].double().cpu(), ref["Xs"], atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,T,Dy,Dhs", [(2, 7, 1, [8]), (3, 40, 2, [32]), (2, 11, 1, [16, 8]), (2, 9, 3, [64, 32])])
+def test_bilstm_encoder(built_lib, B, T, Dy, Dhs):
+    """persistent bi-LSTM kernel (psvo_bilstm_forward) vs the oracle's LSTMBlockCell restatement"""
+    from psvo_amd.model import StackBiRNN
+    torch.manual_seed(1)
+    enc = Hh.perturb_(StackBiRNN(Dy, Dhs, "y_smoother")).cuda()
+    x = torch.randn(B, T, Dy, dtype=torch.float64)
+    layers = [{"fw": (f.kernel.detach().double().cpu(), f.bias.detach().double().cpu()),
+               "bw": (b.kernel.detach().double().cpu(), b.bias.detach().double().cpu())}
+              for f, b in zip(enc.fw, enc.bw)]
+    ref = O.stack_bidirectional_rnn(x, layers)
+    with torch.no_grad():
+        out = enc(x.float().cuda())
+    assert torch.allclose(out.double().cpu(), ref, atol=2e-5, rtol=1e-5)
