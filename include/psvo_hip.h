@@ -96,8 +96,9 @@ const char* psvo_last_hip_error(void);
  *
  *  outputs: X (T,B,Dx,N) pre-resampling particles (Xs_ta), Xanc (T,B,Dx,N) resampled particles
  *  (X_ancestors_ta), Fm (T,B,Dx,N) = MLP_f(X_t) (transition means of every forward particle,
- *  consumed by the backward simulation), logW (T,B,N) (log_Ws_ta), idx_out (T,B,N) ancestors,
- *  lse (T,B) = logsumexp_n logW[t,b,:].
+ *  consumed by the backward simulation), P1 (T,B,Dx,N) = MLP_q1(X_t) (optional, may be NULL; only
+ *  needed by psvo_filter_backward when !bootstrap), logW (T,B,N) (log_Ws_ta), idx_out (T,B,N)
+ *  ancestors, lse (T,B) = logsumexp_n logW[t,b,:].
  * ------------------------------------------------------------------------------------------- */
 int psvo_filter_forward(const psvo_desc* desc,
                         const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
@@ -105,8 +106,8 @@ int psvo_filter_forward(const psvo_desc* desc,
                         const float* mu2,
                         const float* m0, const float* sig0, const float* fm0, const float* fsig0,
                         const float* obs, const float* eps, const float* u, const int32_t* idx_in,
-                        float* X, float* Xanc, float* Fm, float* logW, int32_t* idx_out, float* lse,
-                        void* stream);
+                        float* X, float* Xanc, float* Fm, float* P1, float* logW, int32_t* idx_out,
+                        float* lse, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward simulation with proposal.  Replaces PSVO.backward_simulation_w_proposal
@@ -137,6 +138,50 @@ int psvo_bsim_forward(const psvo_desc* desc,
                       const float* obs, const float* eps_b, const float* u_b, const int32_t* sel_in,
                       float* bwX, float* flp, float* glp, float* Omega, int32_t* sel_out,
                       float* score, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reverse mode of psvo_filter_forward.  The reference obtains these gradients from TensorFlow
+ * autodiff of the tf.while_loop (reference src/trainer.py:115-118; no stop_gradient in src/,
+ * SURVEY.md Appendix B).  One persistent workgroup per sequence walks t = T-1 .. 0.
+ *
+ *  inputs  : everything psvo_filter_forward took (eps as drawn), its outputs X, Fm, P1 (NULL when
+ *            bootstrap), logW, lse, idx, and the upstream gradients
+ *              dlse      (T,B)              d loss / d lse[t,b]            (NULL = 0)
+ *              dFm_ext   (T,B,nparts,Dx,N)  d loss / d Fm, summed over the `nparts` axis (NULL = 0)
+ *              dlogW_ext (T,B,nparts,N)     d loss / d logW, likewise      (NULL = 0)
+ *            (nparts = workgroups per sequence of psvo_bsim_backward, which writes partials).
+ *  outputs : per-evaluation output gradients for psvo_mlp_wgrad
+ *              dP (T,B,Dx,N) w.r.t. MLP_q1(X_t) (includes the transition share when bootstrap),
+ *              dF (T,B,Dx,N) w.r.t. MLP_f(X_t) (only when !bootstrap), dG (T,B,Dy,N) w.r.t. MLP_g(X_t);
+ *            hoisted-input gradients dmu2 (T,B,Dx), dm0 (B,Dx), dfm0 (B,Dx);
+ *            scale gradients dsig_q1, dsig_q2, dsig_f, dsig0, dfsig0 (Dx), dsig_g (Dy).
+ *  sacc    : workspace, B * psvo_filter_acc_size(Dx, Dy) floats.
+ * ------------------------------------------------------------------------------------------- */
+int psvo_filter_acc_size(int Dx, int Dy);
+int psvo_filter_backward(const psvo_desc* desc,
+                         const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
+                         const float* sig_q1, const float* sig_q2, const float* sig_f, const float* sig_g,
+                         const float* mu2,
+                         const float* m0, const float* sig0, const float* fm0, const float* fsig0,
+                         const float* obs, const float* eps,
+                         const float* X, const float* Fm, const float* P1, const float* logW, const float* lse,
+                         const int32_t* idx,
+                         const float* dlse, int nparts, const float* dFm_ext, const float* dlogW_ext,
+                         float* dP, float* dF, float* dG, float* dmu2, float* dm0, float* dfm0,
+                         float* dsig_q1, float* dsig_q2, float* dsig_f, float* dsig_g, float* dsig0, float* dfsig0,
+                         float* sacc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Parameter gradients of a one-hidden-layer MLP from per-row output gradients:
+ *   grad = [dW1 (Din,H) | db1 (H) | dW2 (H,Dout) | db2 (Dout)]  (keras layout, flat)
+ *   X [S][Din][L], dOut [S][Dout][L]: S segments of L rows ((T,B,D,N) tensors: S = T*B, L = N).
+ *   partial: workspace, psvo_mlp_wgrad_blocks(S*L) * len(grad) floats.  accumulate != 0 adds into grad.
+ * Replaces the dense-layer gradient ops TensorFlow autodiff emits for MLP_transformation
+ * (reference src/transformation/MLP.py:48-68).
+ * ------------------------------------------------------------------------------------------- */
+int psvo_mlp_wgrad_blocks(long long rows);
+int psvo_mlp_wgrad(long long S, int L, int Din, int H, int Dout, const float* X, const float* dOut,
+                   const psvo_mlp* w, float* partial, float* grad, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One bidirectional LSTMBlockCell layer over a batch of sequences -- the observation encoder

@@ -63,7 +63,8 @@ class PSVO(SVO):
 
         with torch.no_grad():
             bs = ops.bsim_forward(
-                self._desc(M), filt, _c(model.f_tran.hip_params()), _c(model.g_tran.hip_params()),
+                self._desc(M), {k: _c(v) for k, v in filt.items() if k in ("X", "Fm", "logW", "lse")},
+                _c(model.f_tran.hip_params()), _c(model.g_tran.hip_params()),
                 _c(model.q1_inv_tran.hip_params()), _c(self.f.get_sigma()), _c(self.g.get_sigma()),
                 _c(self.q1_inv.get_sigma()), _c(self.BSim_q2.get_sigma()), _c(bmu2), _c(minit),
                 _c(self.BSim_q_init.get_sigma()), _c(imean), _c(isig), obs_TB, eps_b, u_b, sel_in)

@@ -9,6 +9,7 @@ permutes the result to the reference's (batch, time, particles, Dx).
 import torch
 
 from .. import ops
+from ..autograd import FilterFunction
 
 
 class SVO:
@@ -101,18 +102,20 @@ class SVO:
         if self.resample_particles and u is None and idx_in is None:
             u = self._rand(T, B, N, device=dev)
 
-        f_params = None if model.use_bootstrap else model.f_tran.hip_params()
+        f_params = (None,) * 4 if model.use_bootstrap else model.f_tran.hip_params()
         sig_f = None if model.use_bootstrap else self.f.get_sigma()
-        with torch.no_grad():
-            filt = ops.filter_forward(
-                self._desc(), _c(model.q1_tran.hip_params()), _c(f_params), _c(model.g_tran.hip_params()),
-                _c(self.q1.get_sigma()), _c(sig_q2), _c(sig_f), _c(self.g.get_sigma()),
-                _c(mu2), _c(m0), _c(sig0), _c(fm0), _c(fsig0), obs_TB, eps, u, idx_in)
-        filt["eps"], filt["u"] = eps, u
-        return filt
+        # one opaque autograd node: psvo_filter_forward / psvo_filter_backward
+        lse, Fm, logW, X, Xanc, idx = FilterFunction.apply(
+            self._desc(), obs_TB, eps, u, idx_in,
+            *model.q1_tran.hip_params(), *f_params, *model.g_tran.hip_params(),
+            self.q1.get_sigma(), sig_q2, sig_f, self.g.get_sigma(), mu2, m0, sig0, fm0, fsig0)
+        return {"lse": lse, "Fm": Fm, "logW": logW, "X": X, "Xanc": Xanc, "idx": idx, "eps": eps, "u": u}
 
     def compute_log_ZSMC(self, lse):
-        """SVO.py:302-311: mean_b sum_t logsumexp_n log_Ws[t, n, b]."""
+        """SVO.py:302-311: mean_b sum_t logsumexp_n log_Ws[t, n, b]; `lse` (T, B) is the per-step
+        logsumexp the filter kernel already produced."""
+        if lse.requires_grad:
+            return lse.sum(0).mean()
         return ops.elbo_filter(self._desc(), lse).mean()
 
     def preprocess_obs(self, obs):

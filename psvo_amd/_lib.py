@@ -37,7 +37,12 @@ SIGNATURES = {
     "psvo_abi_version": (ctypes.c_int, []),
     "psvo_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "psvo_last_hip_error": (ctypes.c_char_p, []),
-    "psvo_filter_forward": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 19 + [_P]),
+    "psvo_filter_forward": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 20 + [_P]),
+    "psvo_filter_acc_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "psvo_filter_backward": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 18 + [ctypes.c_int] + [_P] * 16),
+    "psvo_mlp_wgrad_blocks": (ctypes.c_int, [ctypes.c_longlong]),
+    "psvo_mlp_wgrad": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      _P, _P, _MLP, _P, _P, ctypes.c_int, _P]),
     "psvo_bsim_forward": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 19 + [_P]),
     "psvo_bilstm_forward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 8 + [_P]),
     "psvo_elbo_filter": (ctypes.c_int, [_DESC, _P, _P, _P]),

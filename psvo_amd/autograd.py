@@ -1,0 +1,60 @@
+"""torch.autograd glue around the HIP forward / backward kernels.
+
+The reference differentiates `-log_ZSMC` with TensorFlow autodiff (src/trainer.py:115-118).  Here
+the per-particle part of the graph (filter, backward simulation) is two opaque nodes whose
+backward passes are hand-written persistent kernels (psvo_filter_backward, psvo_bsim_backward,
+psvo_mlp_wgrad); everything upstream of them (hoisted per-(b, t) proposal means, the encoder,
+softplus/clamp of the scale parameters) stays in torch autograd.
+"""
+import torch
+
+from . import ops
+
+
+def _cf(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+def _cg(t):
+    return None if t is None else t.contiguous()
+
+
+class FilterFunction(torch.autograd.Function):
+    """psvo_filter_forward / psvo_filter_backward.
+
+    apply(desc, obs_TB, eps, u, idx_in,
+          q1W1, q1b1, q1W2, q1b2, fW1, fb1, fW2, fb2, gW1, gb1, gW2, gb2,
+          sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0)
+      -> lse (T,B), Fm (T,B,Dx,N), logW (T,B,N)   [differentiable]
+         X, Xanc (T,B,Dx,N), idx (T,B,N) int32      [constants]
+    f* are None when desc.bootstrap; sig_q2 / mu2 are None when not desc.two_q.
+    """
+
+    @staticmethod
+    def forward(ctx, desc, obs_TB, eps, u, idx_in, *t):
+        t = [_cf(v) for v in t]
+        q1, f, g = tuple(t[0:4]), tuple(t[4:8]), tuple(t[8:12])
+        sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0 = t[12:21]
+        if desc.bootstrap:
+            f = None
+        filt = ops.filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
+                                  obs_TB, eps, u, idx_in)
+        ctx.desc, ctx.filt = desc, filt
+        ctx.saved = (q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs_TB, eps)
+        ctx.mark_non_differentiable(filt["X"], filt["Xanc"], filt["idx"])
+        return filt["lse"], filt["Fm"], filt["logW"], filt["X"], filt["Xanc"], filt["idx"]
+
+    @staticmethod
+    def backward(ctx, dlse, dFm, dlogW, *_):
+        desc = ctx.desc
+        q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs_TB, eps = ctx.saved
+        r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
+                                obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW))
+        Dx, Dy, H = desc.Dx, desc.Dy, desc.H
+        gq1 = ops.split_mlp_grad(r["gq1"], Dx, H, Dx)
+        gf = (None,) * 4 if desc.bootstrap else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
+        gg = ops.split_mlp_grad(r["gg"], Dx, H, Dy)
+        two_q, boot = bool(desc.two_q), bool(desc.bootstrap)
+        return (None, None, None, None, None) + tuple(gq1) + tuple(gf) + tuple(gg) + (
+            r["dsig_q1"], r["dsig_q2"] if two_q else None, None if boot else r["dsig_f"], r["dsig_g"],
+            r["dmu2"] if two_q else None, r["dm0"], r["dsig0"], r["dfm0"], r["dfsig0"])

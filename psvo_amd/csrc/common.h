@@ -94,6 +94,54 @@ struct MlpLds {
             for (int k = 0; k < H; k += 4) group4(w, k, x, out);
         }
     }
+
+    // dx += (d out / d x)^T dout : recomputes the hidden pre-activations (nothing is stored)
+    template <bool ROLLED = false>
+    __device__ __forceinline__ static void bwd_input(const float* __restrict__ w, const float (&x)[DIN],
+                                                     const float (&dout)[DOUT], float (&dx)[DIN]) {
+        auto g4 = [&](int k) {
+            float4 pre = *reinterpret_cast<const float4*>(w + kB1 + k);
+            float4 wi[DIN];
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) {
+                wi[i] = *reinterpret_cast<const float4*>(w + kW1 + i * H + k);
+                pre.x = fmaf(x[i], wi[i].x, pre.x);
+                pre.y = fmaf(x[i], wi[i].y, pre.y);
+                pre.z = fmaf(x[i], wi[i].z, pre.z);
+                pre.w = fmaf(x[i], wi[i].w, pre.w);
+            }
+            float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int o = 0; o < DOUT; ++o) {
+                const float4 wo = *reinterpret_cast<const float4*>(w + kW2 + o * H + k);
+                dh.x = fmaf(dout[o], wo.x, dh.x);
+                dh.y = fmaf(dout[o], wo.y, dh.y);
+                dh.z = fmaf(dout[o], wo.z, dh.z);
+                dh.w = fmaf(dout[o], wo.w, dh.w);
+            }
+            dh.x = pre.x > 0.f ? dh.x : 0.f;
+            dh.y = pre.y > 0.f ? dh.y : 0.f;
+            dh.z = pre.z > 0.f ? dh.z : 0.f;
+            dh.w = pre.w > 0.f ? dh.w : 0.f;
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) {
+                dx[i] = fmaf(dh.x, wi[i].x, dx[i]);
+                dx[i] = fmaf(dh.y, wi[i].y, dx[i]);
+                dx[i] = fmaf(dh.z, wi[i].z, dx[i]);
+                dx[i] = fmaf(dh.w, wi[i].w, dx[i]);
+            }
+        };
+        if constexpr (ROLLED && (H % 8 == 0) && (H > 8)) {
+#pragma unroll 1
+            for (int k = 0; k < H; k += 8) {
+                g4(k);
+                g4(k + 4);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < H; k += 4) g4(k);
+        }
+    }
 };
 
 // diagonal-Gaussian log density given inverse scales and the constant -sum(log s) - D/2 log 2pi

@@ -1,0 +1,427 @@
+// Reverse-mode pass of the forward particle filter (gradient of anything computed from the
+// filter's logW / lse / Fm outputs w.r.t. its inputs).  The reference gets this from TensorFlow
+// autodiff through tf.while_loop (reference src/trainer.py:115-118, no stop_gradient anywhere,
+// SURVEY.md Appendix B); here it is one persistent workgroup per sequence walking t = T-1 .. 0.
+//
+// What flows (Appendix B): samples are reparameterised (x = mu + c*eps), ancestor indices are
+// constants, the gather of resampled particles back-propagates as a scatter-add into the
+// pre-resampling particles.  In this formulation a resampled particle only enters step t+1
+// through the gathered MLP outputs P1_t[a] (proposal mean) and Fm_t[a] (transition mean), so the
+// scatter-add targets are d P1_t / d Fm_t, kept in LDS (float atomics), double-buffered over t.
+//
+// Nothing is stored by the forward pass beyond its own outputs; hidden activations are
+// recomputed.  MLP *weight* gradients are not formed here: the kernel writes, for every MLP
+// evaluation, the gradient w.r.t. that evaluation's output (rows dP, dF, dG) and psvo_mlp_wgrad
+// reduces rows to weights in a fully parallel launch.
+#include "common.h"
+
+namespace psvo {
+
+struct FilterBwdArgs {
+    int B, T, N;
+    int resample, two_q, bootstrap;
+    psvo_mlp q1, f, g;
+    const float *sig_q1, *sig_q2, *sig_f, *sig_g;
+    const float *mu2, *m0, *sig0, *fm0, *fsig0, *obs, *eps;
+    const float *X, *Fm, *P1, *logW, *lse;
+    const int32_t* idx;
+    const float* dlse;       // (T,B) or null
+    int nparts;              // leading "parts" dimension of the external gradients (bsim blocks per sequence)
+    const float* dFm_ext;    // (T,B,nparts,Dx,N) or null
+    const float* dlogW_ext;  // (T,B,nparts,N) or null
+    float *dP, *dF, *dG, *dmu2, *dm0, *dfm0;
+    float* sacc;             // (B, NACC) per-sequence scalar accumulators (see finalize)
+};
+
+template <int DX, int DY>
+struct FAcc {
+    // per-dimension sums, one set for t >= 1 and one for t = 0
+    static constexpr int kSc = 0;            // direct d c
+    static constexpr int kSmm1 = DX;         // sum dmu * mean1
+    static constexpr int kSmb = 2 * DX;      // sum dmu * mu2
+    static constexpr int kSmm = 3 * DX;      // sum dmu * mu
+    static constexpr int kSfs = 4 * DX;      // direct d (transition scale)
+    static constexpr int kSet = 5 * DX;
+    static constexpr int kSg = 2 * kSet;     // d sigma_g (DY)
+    static constexpr int kN = 2 * kSet + DY;
+};
+
+template <int DX>
+struct BStepK {
+    float c[DX], ic[DX], i1[DX], i2[DX], ifs[DX];
+};
+
+template <int DX>
+__device__ __forceinline__ BStepK<DX> make_bstepk(const float* s1, const float* s2, const float* fs, bool two_q) {
+    BStepK<DX> K;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        K.i1[d] = 1.f / s1[d];
+        if (two_q) {
+            K.i2[d] = 1.f / s2[d];
+            K.ic[d] = K.i1[d] + K.i2[d];
+            K.c[d] = 1.f / K.ic[d];
+        } else {
+            K.i2[d] = 0.f;
+            K.ic[d] = K.i1[d];
+            K.c[d] = s1[d];
+        }
+        K.ifs[d] = 1.f / fs[d];
+    }
+    return K;
+}
+
+// sum of `v` over the whole workgroup, result in every lane; `red` has 16 floats
+__device__ __forceinline__ float block_sum(float v, float* red, int wave, int lane, int nw) {
+    v = wave_sum(v);
+    if (nw == 1) return v;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    __syncthreads();
+    return s;
+}
+
+template <int DX, int DY, int H, int MAXT>
+__global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    using AC = FAcc<DX, DY>;
+    constexpr bool kRolled = true;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = blockDim.x, nw = NT >> 6;
+    const int b = blockIdx.x, B = a.B, T = a.T, N = a.N;
+    const bool valid = tid < N;
+    const int n = valid ? tid : N - 1;
+
+    float* wq1 = smem;
+    float* wf = wq1 + MQ::kSize;
+    float* wg = wf + MQ::kSize;
+    float* accP = wg + MG::kSize;        // [2][DX][NT] scatter targets d P1 (+ d Fm when bootstrap)
+    float* accF = accP + 2 * DX * NT;    // [2][DX][NT] d Fm (only when !bootstrap)
+    float* red = accF + 2 * DX * NT;     // 16 floats
+
+    MQ::load(wq1, a.q1, tid, NT);
+    if (!a.bootstrap) MQ::load(wf, a.f, tid, NT);
+    MG::load(wg, a.g, tid, NT);
+    const float* wfm = a.bootstrap ? wq1 : wf;
+    for (int i = tid; i < 4 * DX * NT; i += NT) accP[i] = 0.f;
+
+    float sq1[DX], sq2[DX], sfv[DX], s0[DX], fs0[DX], isg[DY];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        sq1[d] = a.sig_q1[d];
+        sq2[d] = a.two_q ? a.sig_q2[d] : 1.f;
+        sfv[d] = a.bootstrap ? a.sig_q1[d] : a.sig_f[d];
+        s0[d] = a.sig0[d];
+        fs0[d] = a.fsig0[d];
+    }
+#pragma unroll
+    for (int e = 0; e < DY; ++e) isg[e] = 1.f / a.sig_g[e];
+    const BStepK<DX> K0 = make_bstepk<DX>(s0, sq2, fs0, a.two_q != 0);
+    const BStepK<DX> K1 = make_bstepk<DX>(sq1, sq2, sfv, a.two_q != 0);
+
+    float acc[AC::kN];
+#pragma unroll
+    for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
+    float dlnw = 0.f;  // IWAE: gradient w.r.t. the normalised log-weight carried into step t+1
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t tb = (size_t)t * B + b;
+        const bool first = (t == 0);
+        const BStepK<DX> K = first ? K0 : K1;
+        float inc[AC::kSet];  // this step's contribution to the per-dimension sums (set chosen below)
+#pragma unroll
+        for (int i = 0; i < AC::kSet; ++i) inc[i] = 0.f;
+        float* curP = accP + (t & 1) * DX * NT;
+        float* nxtP = accP + ((t + 1) & 1) * DX * NT;
+        float* curF = accF + (t & 1) * DX * NT;
+        float* nxtF = accF + ((t + 1) & 1) * DX * NT;
+
+        // ---- forward quantities of this step ---------------------------------------------------
+        float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX];
+        int anc = n;
+        if (!first && a.resample) anc = a.idx[(tb - B) * N + n];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            x[d] = a.X[(tb * DX + d) * N + n];
+            e[d] = a.eps[(tb * DX + d) * N + n];
+            m2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
+            if (first) {
+                mean1[d] = a.m0[b * DX + d];
+                fmean[d] = a.fm0[b * DX + d];
+            } else {
+                fmean[d] = a.Fm[((tb - B) * DX + d) * N + anc];
+                mean1[d] = a.bootstrap ? fmean[d] : a.P1[((tb - B) * DX + d) * N + anc];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+        float mu[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d)
+            mu[d] = a.two_q ? K.c[d] * fmaf(K.i1[d], mean1[d], K.i2[d] * m2[d]) : mean1[d];
+
+        // ---- gradient w.r.t. logW_t[n] ------------------------------------------------------------
+        const float sm = valid ? expf(a.logW[tb * N + n] - a.lse[tb]) : 0.f;
+        float dlw = a.dlse ? a.dlse[tb] * sm : 0.f;
+        if (a.dlogW_ext)
+            for (int p = 0; p < a.nparts; ++p) dlw += a.dlogW_ext[(tb * a.nparts + p) * N + n];
+        if (!a.resample) {
+            const float tot = block_sum(dlnw, red, wave, lane, nw);
+            dlw += dlnw - sm * tot;
+        }
+        if (!valid) dlw = 0.f;
+        dlnw = first ? 0.f : dlw;
+
+        // ---- emission ---------------------------------------------------------------------------
+        float dx[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) dx[d] = 0.f;
+        {
+            float gm[DY], dgm[DY];
+            MG::template eval<kRolled>(wg, x, gm);
+#pragma unroll
+            for (int k = 0; k < DY; ++k) {
+                const float z = (y[k] - gm[k]) * isg[k];
+                dgm[k] = dlw * z * isg[k];
+                acc[AC::kSg + k] += dlw * (z * z - 1.f) * isg[k];
+                if (valid) a.dG[(tb * DY + k) * N + n] = dgm[k];
+            }
+            MG::template bwd_input<kRolled>(wg, x, dgm, dx);
+        }
+        // ---- transition and proposal densities ------------------------------------------------------
+        float dfmean[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            const float z = (x[d] - fmean[d]) * K.ifs[d];
+            const float tf = dlw * z * K.ifs[d];
+            dx[d] -= tf;
+            dfmean[d] = tf;
+            inc[AC::kSfs + d] += dlw * (z * z - 1.f) * K.ifs[d];
+            inc[AC::kSc + d] += dlw * K.ic[d];  // -dq/dc = +dlw / c
+        }
+        // ---- MLP_q1(x_t), MLP_f(x_t): gradients scattered here by step t+1 (+ backward simulation) --------
+        float dPn[DX], dFn[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            dPn[d] = curP[d * NT + tid];
+            curP[d * NT + tid] = 0.f;
+            float ext = 0.f;
+            if (a.dFm_ext)
+                for (int p = 0; p < a.nparts; ++p) ext += a.dFm_ext[((tb * a.nparts + p) * DX + d) * N + n];
+            if (a.bootstrap) {
+                dPn[d] += ext;
+                dFn[d] = 0.f;
+            } else {
+                dFn[d] = curF[d * NT + tid] + ext;
+                curF[d * NT + tid] = 0.f;
+            }
+            if (!valid) {
+                dPn[d] = 0.f;
+                dFn[d] = 0.f;
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                a.dP[(tb * DX + d) * N + n] = dPn[d];
+                if (!a.bootstrap) a.dF[(tb * DX + d) * N + n] = dFn[d];
+            }
+        }
+        MQ::template bwd_input<kRolled>(wq1, x, dPn, dx);
+        if (!a.bootstrap) MQ::template bwd_input<kRolled>(wfm, x, dFn, dx);
+
+        // ---- x = mu + c eps, mu = c (mean1/s1 + mu2/s2) ----------------------------------------------------
+        float dmean1[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            const float dmu = dx[d];
+            inc[AC::kSc + d] += dmu * e[d];
+            float dm2 = 0.f;
+            if (a.two_q) {
+                dmean1[d] = dmu * K.c[d] * K.i1[d];
+                dm2 = dmu * K.c[d] * K.i2[d];
+                inc[AC::kSmm1 + d] += dmu * mean1[d];
+                inc[AC::kSmb + d] += dmu * m2[d];
+                inc[AC::kSmm + d] += dmu * mu[d];
+                const float s = block_sum(dm2, red, wave, lane, nw);
+                if (tid == 0) a.dmu2[tb * DX + d] = s;
+            } else {
+                dmean1[d] = dmu;
+            }
+        }
+        // ---- gather backward: scatter-add into the parents (SVO.py:255-257) ------------------------------
+        if (!first) {
+            if (valid) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    if (a.bootstrap) {
+                        atomicAdd(&nxtP[d * NT + anc], dmean1[d] + dfmean[d]);
+                    } else {
+                        atomicAdd(&nxtP[d * NT + anc], dmean1[d]);
+                        atomicAdd(&nxtF[d * NT + anc], dfmean[d]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                const float s1 = block_sum(dmean1[d], red, wave, lane, nw);
+                const float s2 = block_sum(dfmean[d], red, wave, lane, nw);
+                if (tid == 0) {
+                    a.dm0[b * DX + d] = s1;
+                    a.dfm0[b * DX + d] = s2;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AC::kSet; ++i) {  // set 0: t = 0, set 1: t >= 1 (static register indices)
+            acc[i] += first ? inc[i] : 0.f;
+            acc[AC::kSet + i] += first ? 0.f : inc[i];
+        }
+        __syncthreads();
+    }
+
+    // ---- per-sequence scalar accumulators ---------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < AC::kN; ++i) {
+        const float s = block_sum(acc[i], red, wave, lane, nw);
+        if (tid == 0) a.sacc[(size_t)b * AC::kN + i] = s;
+    }
+}
+
+// Finalize: fold the (B, NACC) sums into gradients of the scale vectors.
+//   two_q: c = 1/(1/s1 + 1/s2);  d c = Sc + Smm / c;  d(1/s1) = c*Smm1 - c^2 dc;  d(1/s2) = c*Smb - c^2 dc
+//   else : d s1 = Sc
+template <int DX, int DY>
+__global__ void filter_bwd_finalize(const float* __restrict__ sacc, int B, int two_q, int bootstrap,
+                                    const float* sig_q1, const float* sig_q2, const float* sig0,
+                                    float* dsig_q1, float* dsig_q2, float* dsig_f, float* dsig_g, float* dsig0,
+                                    float* dfsig0) {
+    using AC = FAcc<DX, DY>;
+    const int d = threadIdx.x;
+    if (d < DX) {
+        float S[2 * AC::kSet];
+        for (int i = 0; i < 2 * AC::kSet; ++i) S[i] = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < 2 * AC::kSet; ++i) S[i] += sacc[(size_t)b * AC::kN + i];
+        float ds2 = 0.f;
+        for (int set = 0; set < 2; ++set) {  // set 0: t = 0 (sig0), set 1: t >= 1 (sig_q1)
+            const float* P = S + set * AC::kSet;
+            const float s1 = set ? sig_q1[d] : sig0[d];
+            float ds1;
+            if (two_q) {
+                const float i1 = 1.f / s1, i2 = 1.f / sig_q2[d];
+                const float c = 1.f / (i1 + i2);
+                const float dc = P[AC::kSc + d] + P[AC::kSmm + d] / c;
+                const float di1 = c * P[AC::kSmm1 + d] - c * c * dc;
+                const float di2 = c * P[AC::kSmb + d] - c * c * dc;
+                ds1 = -i1 * i1 * di1;
+                ds2 += -i2 * i2 * di2;
+            } else {
+                ds1 = P[AC::kSc + d];
+            }
+            const float dfs = P[AC::kSfs + d];
+            if (set) {
+                dsig_q1[d] = ds1 + (bootstrap ? dfs : 0.f);
+                dsig_f[d] = bootstrap ? 0.f : dfs;
+            } else {
+                dsig0[d] = ds1;
+                dfsig0[d] = dfs;
+            }
+        }
+        dsig_q2[d] = ds2;
+    }
+    if (d < DY) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += sacc[(size_t)b * AC::kN + AC::kSg + d];
+        dsig_g[d] = s;
+    }
+}
+
+struct FilterBwdOut {
+    float *dsig_q1, *dsig_q2, *dsig_f, *dsig_g, *dsig0, *dfsig0;
+};
+
+template <int DX, int DY, int H>
+static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipStream_t stream) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    const int NT = (a.N + 63) & ~63;
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 4 * DX * NT + 16);
+    clear_hip_error();
+    if (NT <= 256)
+        hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, a);
+    else
+        hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((filter_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc, a.B, a.two_q, a.bootstrap,
+                       a.sig_q1, a.sig_q2, a.sig0, o.dsig_q1, o.dsig_q2, o.dsig_f, o.dsig_g, o.dsig0, o.dfsig0);
+    return launch_status();
+}
+
+template <int DX, int DY>
+static int fb_dispatch_h(const FilterBwdArgs& a, const FilterBwdOut& o, int H, hipStream_t s) {
+    switch (H) {
+        case 16: return launch_filter_bwd<DX, DY, 16>(a, o, s);
+        case 32: return launch_filter_bwd<DX, DY, 32>(a, o, s);
+        case 64: return launch_filter_bwd<DX, DY, 64>(a, o, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+template <int DX>
+static int fb_dispatch_dy(const FilterBwdArgs& a, const FilterBwdOut& o, int Dy, int H, hipStream_t s) {
+    switch (Dy) {
+        case 1: return fb_dispatch_h<DX, 1>(a, o, H, s);
+        case 2: return fb_dispatch_h<DX, 2>(a, o, H, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace psvo
+
+extern "C" int psvo_filter_acc_size(int Dx, int Dy) { return 10 * Dx + Dy; }
+
+extern "C" int psvo_filter_backward(
+    const psvo_desc* desc, const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g, const float* sig_q1,
+    const float* sig_q2, const float* sig_f, const float* sig_g, const float* mu2, const float* m0, const float* sig0,
+    const float* fm0, const float* fsig0, const float* obs, const float* eps, const float* X, const float* Fm,
+    const float* P1, const float* logW, const float* lse, const int32_t* idx, const float* dlse, int nparts,
+    const float* dFm_ext, const float* dlogW_ext, float* dP, float* dF, float* dG, float* dmu2, float* dm0,
+    float* dfm0, float* dsig_q1, float* dsig_q2, float* dsig_f, float* dsig_g, float* dsig0, float* dfsig0,
+    float* sacc, void* stream) {
+    using namespace psvo;
+    if (!desc || !q1 || !g || !sig_q1 || !sig_g || !m0 || !sig0 || !fm0 || !fsig0 || !obs || !eps || !X || !Fm ||
+        !logW || !lse || !dP || !dG || !dm0 || !dfm0 || !dsig_q1 || !dsig_q2 || !dsig_f || !dsig_g || !dsig0 ||
+        !dfsig0 || !sacc)
+        return PSVO_ERR_INVALID;
+    if (desc->B <= 0 || desc->T <= 0 || desc->N <= 0) return PSVO_ERR_INVALID;
+    if (desc->two_q && (!mu2 || !sig_q2 || !dmu2)) return PSVO_ERR_INVALID;
+    if (!desc->bootstrap && (!f || !sig_f || !P1 || !dF)) return PSVO_ERR_INVALID;
+    if (desc->resample && !idx) return PSVO_ERR_INVALID;
+    if ((dFm_ext || dlogW_ext) && nparts <= 0) return PSVO_ERR_INVALID;
+    if (desc->N > 512) return PSVO_ERR_UNSUPPORTED;
+
+    FilterBwdArgs a;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N;
+    a.resample = desc->resample; a.two_q = desc->two_q; a.bootstrap = desc->bootstrap;
+    a.q1 = *q1; a.f = desc->bootstrap ? *q1 : *f; a.g = *g;
+    a.sig_q1 = sig_q1; a.sig_q2 = sig_q2; a.sig_f = sig_f; a.sig_g = sig_g;
+    a.mu2 = mu2; a.m0 = m0; a.sig0 = sig0; a.fm0 = fm0; a.fsig0 = fsig0; a.obs = obs; a.eps = eps;
+    a.X = X; a.Fm = Fm; a.P1 = P1; a.logW = logW; a.lse = lse; a.idx = idx;
+    a.dlse = dlse; a.nparts = nparts; a.dFm_ext = dFm_ext; a.dlogW_ext = dlogW_ext;
+    a.dP = dP; a.dF = dF; a.dG = dG; a.dmu2 = dmu2; a.dm0 = dm0; a.dfm0 = dfm0; a.sacc = sacc;
+    FilterBwdOut o{dsig_q1, dsig_q2, dsig_f, dsig_g, dsig0, dfsig0};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (desc->Dx) {
+        case 2: return fb_dispatch_dy<2>(a, o, desc->Dy, desc->H, s);
+        case 3: return fb_dispatch_dy<3>(a, o, desc->Dy, desc->H, s);
+        case 4: return fb_dispatch_dy<4>(a, o, desc->Dy, desc->H, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}

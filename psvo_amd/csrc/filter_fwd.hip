@@ -19,7 +19,7 @@ struct FilterArgs {
     const float *sig_q1, *sig_q2, *sig_f, *sig_g;
     const float *mu2, *m0, *sig0, *fm0, *fsig0, *obs, *eps, *u;
     const int32_t* idx_in;
-    float *X, *Xanc, *Fm, *logW;
+    float *X, *Xanc, *Fm, *P1, *logW;
     int32_t* idx_out;
     float* lse;
 };
@@ -186,6 +186,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
             for (int d = 0; d < DX; ++d) {
                 a.X[(tb * DX + d) * N + n] = x[d];
                 a.Fm[(tb * DX + d) * N + n] = fm[d];
+                if (a.P1) a.P1[(tb * DX + d) * N + n] = p1[d];
             }
             a.logW[tb * N + n] = lw;
         }
@@ -316,7 +317,7 @@ extern "C" int psvo_filter_forward(const psvo_desc* desc, const psvo_mlp* q1, co
                                    const float* sig_q1, const float* sig_q2, const float* sig_f,
                                    const float* sig_g, const float* mu2, const float* m0, const float* sig0,
                                    const float* fm0, const float* fsig0, const float* obs, const float* eps,
-                                   const float* u, const int32_t* idx_in, float* X, float* Xanc, float* Fm,
+                                   const float* u, const int32_t* idx_in, float* X, float* Xanc, float* Fm, float* P1,
                                    float* logW, int32_t* idx_out, float* lse, void* stream) {
     using namespace psvo;
     if (!desc || !q1 || !g || !sig_q1 || !sig_g || !m0 || !sig0 || !fm0 || !fsig0 || !obs || !eps || !X ||
@@ -335,7 +336,7 @@ extern "C" int psvo_filter_forward(const psvo_desc* desc, const psvo_mlp* q1, co
     a.sig_q1 = sig_q1; a.sig_q2 = sig_q2; a.sig_f = sig_f; a.sig_g = sig_g;
     a.mu2 = mu2; a.m0 = m0; a.sig0 = sig0; a.fm0 = fm0; a.fsig0 = fsig0;
     a.obs = obs; a.eps = eps; a.u = u; a.idx_in = idx_in;
-    a.X = X; a.Xanc = Xanc; a.Fm = Fm; a.logW = logW; a.idx_out = idx_out; a.lse = lse;
+    a.X = X; a.Xanc = Xanc; a.Fm = Fm; a.P1 = P1; a.logW = logW; a.idx_out = idx_out; a.lse = lse;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {
         case 2: return dispatch_dy<2>(a, desc->Dy, desc->H, s);

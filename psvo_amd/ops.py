@@ -75,13 +75,14 @@ def filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, 
         "X": torch.empty(T, B, Dx, N, device=dev), "Xanc": torch.empty(T, B, Dx, N, device=dev),
         "Fm": torch.empty(T, B, Dx, N, device=dev), "logW": torch.empty(T, B, N, device=dev),
         "idx": torch.empty(T, B, N, device=dev, dtype=torch.int32), "lse": torch.empty(T, B, device=dev),
+        "P1": None if desc.bootstrap else torch.empty(T, B, Dx, N, device=dev),
     }
     st = lib.psvo_filter_forward(
         ctypes.byref(desc), ctypes.byref(q1s), ctypes.byref(fs) if fs is not None else None, ctypes.byref(gs),
         _ptr(sig_q1), _ptr(sig_q2), _ptr(sig_f), _ptr(sig_g), _ptr(mu2), _ptr(m0), _ptr(sig0), _ptr(fm0),
         _ptr(fsig0), _ptr(obs), _ptr(eps), _ptr(u), _ptr(idx_in),
-        _ptr(out["X"]), _ptr(out["Xanc"]), _ptr(out["Fm"]), _ptr(out["logW"]), _ptr(out["idx"]), _ptr(out["lse"]),
-        _stream())
+        _ptr(out["X"]), _ptr(out["Xanc"]), _ptr(out["Fm"]), _ptr(out["P1"]), _ptr(out["logW"]), _ptr(out["idx"]),
+        _ptr(out["lse"]), _stream())
     _lib.check(st, "psvo_filter_forward")
     return out
 
@@ -155,3 +156,75 @@ def bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=False):
                                  _ptr(out), _ptr(cs), _ptr(gates), _stream())
     _lib.check(st, "psvo_bilstm_forward")
     return (out, cs, gates) if save else out
+
+
+def mlp_wgrad(X, dOut, w, Din, H, Dout, grad=None):
+    """psvo_mlp_wgrad: rows X [S][Din][L], dOut [S][Dout][L] -> flat grad [dW1|db1|dW2|db2].
+    X / dOut are any contiguous tensors whose leading dims flatten to S and whose last dim(s)
+    flatten to L, e.g. (T,B,Din,N) or (T,B,Din,N,M)."""
+    lib = _lib.load()
+    dev = X.device
+    if X.dim() < 3 or not X.is_contiguous() or not dOut.is_contiguous():
+        raise ValueError("mlp_wgrad wants contiguous [S..., D, L...] tensors")
+    # locate the feature axis: X has Din there, dOut has Dout
+    ax = None
+    for i in range(X.dim()):
+        if X.shape[i] == Din and dOut.shape[i] == Dout and X.shape[:i] == dOut.shape[:i] and X.shape[i + 1:] == dOut.shape[i + 1:]:
+            ax = i
+    if ax is None:
+        raise ValueError("mlp_wgrad: cannot match shapes %s / %s to Din=%d, Dout=%d" % (tuple(X.shape), tuple(dOut.shape), Din, Dout))
+    S = 1
+    for v in X.shape[:ax]:
+        S *= v
+    L = 1
+    for v in X.shape[ax + 1:]:
+        L *= v
+    ws = _mlp_struct(w, Din, H, Dout, "w")
+    NP = Din * H + H + H * Dout + Dout
+    nblk = lib.psvo_mlp_wgrad_blocks(S * L)
+    partial = torch.empty(nblk, NP, device=dev)
+    acc = grad is not None
+    if grad is None:
+        grad = torch.empty(NP, device=dev)
+    st = lib.psvo_mlp_wgrad(S, L, Din, H, Dout, _ptr(X), _ptr(dOut), ctypes.byref(ws), _ptr(partial), _ptr(grad),
+                            int(acc), _stream())
+    _lib.check(st, "psvo_mlp_wgrad")
+    return grad
+
+
+def split_mlp_grad(g, Din, H, Dout):
+    """flat [dW1|db1|dW2|db2] -> (dW1 (Din,H), db1 (H), dW2 (H,Dout), db2 (Dout)) views."""
+    a = Din * H
+    return (g[:a].view(Din, H), g[a:a + H], g[a + H:a + H + H * Dout].view(H, Dout), g[a + H + H * Dout:])
+
+
+def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs, eps, filt,
+                    dlse=None, dFm=None, dlogW=None):
+    """psvo_filter_backward + psvo_mlp_wgrad.  `filt` = forward outputs.  dFm (T,B,Dx,N) / dlogW (T,B,N)
+    are upstream gradients (or None).  Returns a dict of gradients."""
+    lib = _lib.load()
+    B, T, N, Dx, Dy, H = desc.B, desc.T, desc.N, desc.Dx, desc.Dy, desc.H
+    dev = eps.device
+    q1s = _mlp_struct(q1, Dx, H, Dx, "q1")
+    fs = None if desc.bootstrap else _mlp_struct(f, Dx, H, Dx, "f")
+    gs = _mlp_struct(g, Dx, H, Dy, "g")
+    _chk(dlse, (T, B), "dlse"); _chk(dFm, (T, B, Dx, N), "dFm"); _chk(dlogW, (T, B, N), "dlogW")
+    z = lambda *s: torch.empty(*s, device=dev)
+    out = {"dP": z(T, B, Dx, N), "dF": None if desc.bootstrap else z(T, B, Dx, N), "dG": z(T, B, Dy, N),
+           "dmu2": z(T, B, Dx) if desc.two_q else None, "dm0": z(B, Dx), "dfm0": z(B, Dx),
+           "dsig_q1": z(Dx), "dsig_q2": z(Dx), "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig0": z(Dx), "dfsig0": z(Dx)}
+    sacc = z(B, lib.psvo_filter_acc_size(Dx, Dy))
+    nparts = 1 if (dFm is not None or dlogW is not None) else 0
+    st = lib.psvo_filter_backward(
+        ctypes.byref(desc), ctypes.byref(q1s), ctypes.byref(fs) if fs is not None else None, ctypes.byref(gs),
+        _ptr(sig_q1), _ptr(sig_q2), _ptr(sig_f), _ptr(sig_g), _ptr(mu2), _ptr(m0), _ptr(sig0), _ptr(fm0), _ptr(fsig0),
+        _ptr(obs), _ptr(eps), _ptr(filt["X"]), _ptr(filt["Fm"]), _ptr(filt["P1"]), _ptr(filt["logW"]),
+        _ptr(filt["lse"]), _ptr(filt["idx"]), _ptr(dlse), nparts, _ptr(dFm), _ptr(dlogW),
+        _ptr(out["dP"]), _ptr(out["dF"]), _ptr(out["dG"]), _ptr(out["dmu2"]), _ptr(out["dm0"]), _ptr(out["dfm0"]),
+        _ptr(out["dsig_q1"]), _ptr(out["dsig_q2"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig0"]),
+        _ptr(out["dfsig0"]), _ptr(sacc), _stream())
+    _lib.check(st, "psvo_filter_backward")
+    out["gq1"] = mlp_wgrad(filt["X"], out["dP"], q1, Dx, H, Dx)
+    out["gf"] = None if desc.bootstrap else mlp_wgrad(filt["X"], out["dF"], f, Dx, H, Dx)
+    out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy)
+    return out

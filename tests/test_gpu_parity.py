@@ -119,3 +119,94 @@ def test_bilstm_encoder(built_lib, B, T, Dy, Dhs):
     with torch.no_grad():
         out = enc(x.float().cuda())
     assert torch.allclose(out.double().cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# gradients: hand-written backward kernels vs torch autograd of the fp64 oracle
+# ---------------------------------------------------------------------------------------------
+def _oracle_grads(model, FLAGS, obj, obs, noise, teacher):
+    P = model.export_reference_layout(torch.float64)
+    leaves = []
+
+    def req(x):
+        if torch.is_tensor(x):
+            x.requires_grad_(True)
+            leaves.append(x)
+        elif isinstance(x, dict):
+            [req(v) for v in x.values()]
+        elif isinstance(x, (list, tuple)):
+            [req(v) for v in x]
+    req(P)
+    o = O.OBJECTIVES[obj](P, Hh.oracle_flags(FLAGS, obj))
+    z, _ = o.get_log_ZSMC(obs.double(), {**noise, **teacher})
+    z.backward()
+    return z.detach(), P
+
+
+def _pairs(model, P):
+    """(name, product parameter, oracle tensor) for every trainable variable"""
+    out = []
+
+    def dist(name, d):
+        tr = d.transformation
+        for i, (W, b) in enumerate(zip(tr.kernels, tr.biases)):
+            out.append((name + ".W%d" % i, W, P[name]["layers"][i][0]))
+            out.append((name + ".b%d" % i, b, P[name]["layers"][i][1]))
+        out.append((name + ".Wmu", tr.mu_kernel, P[name]["mu"][0]))
+        out.append((name + ".bmu", tr.mu_bias, P[name]["mu"][1]))
+        out.append((name + ".sigma", d.sigma_con, P[name]["sigma_raw"]))
+    dist("q0", model.q0_dist); dist("q1", model.q1_dist); dist("g", model.g_dist)
+    if model.use_2_q:
+        dist("q2", model.q2_dist)
+    if not model.use_bootstrap:
+        dist("f", model.f_dist)
+    if not (model.use_bootstrap and model.use_2_q):
+        out.append(("X0_transformer.W", model.X0_transformer_kernel, P["X0_transformer"][0]))
+        out.append(("X0_transformer.b", model.X0_transformer_bias, P["X0_transformer"][1]))
+    if model.PSVO:
+        dist("BSim_q_init", model.Bsim_q_init_dist); dist("q1_inv", model.q1_inv_dist)
+        dist("BSim_q2", model.BSim_q2_dist)
+    if model.bRNN is not None:
+        for nm, s in (("y_smoother", model.y_smoother), ("X0_smoother", model.X0_smoother)):
+            if s is None:
+                continue
+            for i, (f, b) in enumerate(zip(s.fw, s.bw)):
+                out.append(("%s.fw%d.W" % (nm, i), f.kernel, P["bRNN"][nm][i]["fw"][0]))
+                out.append(("%s.fw%d.b" % (nm, i), f.bias, P["bRNN"][nm][i]["fw"][1]))
+                out.append(("%s.bw%d.W" % (nm, i), b.kernel, P["bRNN"][nm][i]["bw"][0]))
+                out.append(("%s.bw%d.b" % (nm, i), b.bias, P["bRNN"][nm][i]["bw"][1]))
+    return out
+
+
+def _check_grads(model, P, rtol=2e-3):
+    bad = []
+    for name, p, ref in _pairs(model, P):
+        g = torch.zeros_like(ref) if p.grad is None else p.grad.detach().double().cpu()
+        r = torch.zeros_like(ref) if ref.grad is None else ref.grad
+        scale = max(r.abs().max().item(), 1e-6)
+        err = (g - r).abs().max().item()
+        if err > rtol * scale + 1e-6:
+            bad.append((name, err, scale))
+    assert not bad, "gradient mismatch (name, max abs err, ref scale): %s" % bad
+
+
+GRAD_CASES = [c for c in CASES if c[0] != "PSVO"]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_filter_gradients(built_lib, case):
+    """d log_ZSMC / d(all parameters) for SVO / AESMC / IWAE, teacher-forced ancestors."""
+    obj = case[0]
+    FLAGS, model, smc, obs, noise = _setup(*case, seed=5)
+    _, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
+    teacher = {"idx_f": ref0["idx_f"]} if ref0["idx_f"] is not None else {}
+    z_ref, P = _oracle_grads(model, FLAGS, obj, obs, noise, teacher)
+    nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
+    if "idx_f" in nz:
+        nz.pop("u_f", None)
+    model.zero_grad()
+    z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
+    z.backward()
+    torch.cuda.synchronize()
+    assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+    _check_grads(model, P)
