@@ -126,8 +126,10 @@ int psvo_filter_forward(const psvo_desc* desc,
  *
  *  outputs: bwX (T,B,Dx,N) (bw_Xs), flp (T,B,N) (f_log_probs), glp (T,B,N) (g_log_probs),
  *  Omega (T,B,N) (bw_log_Omegas), sel_out (T,B,N) chosen sub-particle, score (B,N) =
- *  sum_t(flp+glp-Omega), elbo_b (B) = logsumexp_n score - log N (PSVO.compute_log_ZSMC :52-67
- *  before the batch mean).
+ *  sum_t(flp+glp-Omega) (psvo_elbo_bsim turns it into logsumexp_n score - log N, PSVO.py:52-67).
+ *  lam2_all (T,B,N,M), om_all (T,B,N,M), mu1_all (T,B,Dx,N): optional (NULL) saves for
+ *  psvo_bsim_backward -- the log2-domain filter term, the normalised sub-particle log-weights and
+ *  MLP_q1inv(bwX[t+1]).
  * ------------------------------------------------------------------------------------------- */
 int psvo_bsim_forward(const psvo_desc* desc,
                       const float* X, const float* Fm, const float* logW, const float* lse,
@@ -137,7 +139,43 @@ int psvo_bsim_forward(const psvo_desc* desc,
                       const float* imean, const float* isig,
                       const float* obs, const float* eps_b, const float* u_b, const int32_t* sel_in,
                       float* bwX, float* flp, float* glp, float* Omega, int32_t* sel_out,
-                      float* score, void* stream);
+                      float* score,
+                      float* lam2_all, float* om_all, float* mu1_all,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reverse mode of psvo_bsim_forward (TensorFlow autodiff of PSVO.backward_simulation_w_proposal in
+ * the reference, src/trainer.py:115-118).  The N x N tile is recomputed, not stored.
+ *
+ *  inputs  : the forward call's inputs (eps_b as drawn), its outputs bwX, sel and the three optional
+ *            saves lam2_all (T,B,N,M), om_all (T,B,N,M), mu1_all (T,B,Dx,N) (required here), and
+ *            dscore (B,N) = d loss / d score.
+ *  outputs : rows for psvo_mlp_wgrad: xt (T,B,Dx,N,M) sub-particles, dFt (T,B,Dx,N,M) w.r.t.
+ *            MLP_f(x~), dGt (T,B,Dy,N,M) w.r.t. MLP_g(x~), dmu1 (T,B,Dx,N) w.r.t. MLP_q1inv(bwX[t+1]);
+ *            per-workgroup partials (nblk = psvo_bsim_blocks(N, M), to be summed over that axis):
+ *            dFm_part (T,B,nblk,Dx,N), dlogW_part (T,B,nblk,N)  -> psvo_filter_backward,
+ *            dbmu2_part (T,B,nblk,Dx), dminit_part (B,nblk,Dx), dimean_part (B,nblk,Dx);
+ *            scale gradients dsig_f, dsig_q1inv, dsig_bq2, dsig_init, disig (Dx), dsig_g (Dy).
+ *  sacc_part: workspace, B * nblk * psvo_bsim_acc_size(Dx, Dy) floats.
+ *  The gradient w.r.t. lse is identically zero (the normalised weights' gradients sum to zero).
+ * ------------------------------------------------------------------------------------------- */
+int psvo_bsim_blocks(int N, int M);
+int psvo_bsim_acc_size(int Dx, int Dy);
+int psvo_bsim_backward(const psvo_desc* desc,
+                       const float* Fm, const float* logW, const float* lse,
+                       const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
+                       const float* sig_f, const float* sig_g, const float* sig_q1inv, const float* sig_bq2,
+                       const float* bmu2, const float* minit, const float* sig_init,
+                       const float* imean, const float* isig,
+                       const float* obs, const float* eps_b,
+                       const float* bwX, const int32_t* sel,
+                       const float* lam2_all, const float* om_all, const float* mu1_all,
+                       const float* dscore,
+                       float* xt, float* dFt, float* dGt, float* dmu1,
+                       float* dFm_part, float* dlogW_part, float* dbmu2_part, float* dminit_part,
+                       float* dimean_part,
+                       float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
+                       float* disig, float* sacc_part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse mode of psvo_filter_forward.  The reference obtains these gradients from TensorFlow

@@ -1,10 +1,13 @@
 """PSVO -- mirror of reference src/SMC/PSVO.py:8-216: forward filter, then backward simulation
 with proposal.  The backward simulation (PSVO.py:69-203, the (M, N, N, B) transition tile) is
 ONE persistent HIP kernel (psvo_bsim_forward, psvo_amd/csrc/bsim_fwd.hip)."""
+import math
+
 import torch
 
 from .. import ops
-from .SVO import SVO, _c
+from ..autograd import BsimFunction
+from .SVO import SVO
 
 
 class PSVO(SVO):
@@ -35,6 +38,8 @@ class PSVO(SVO):
 
     def compute_log_ZSMC_bsim(self, score):
         """PSVO.py:52-67: mean_b [ logsumexp_n( sum_t(f+g) - sum_t Omega ) - log N ]."""
+        if score.requires_grad:
+            return (torch.logsumexp(score, dim=1) - math.log(float(score.shape[1]))).mean()
         return ops.elbo_bsim(self._desc(self.n_particles_for_BSim_proposal), score).mean()
 
     def backward_simulation_w_proposal(self, filt, obs, noise=None):
@@ -61,14 +66,13 @@ class PSVO(SVO):
             u_b = self._rand(T, B, N, device=dev)
         obs_TB = obs.transpose(0, 1).contiguous().float()
 
-        with torch.no_grad():
-            bs = ops.bsim_forward(
-                self._desc(M), {k: _c(v) for k, v in filt.items() if k in ("X", "Fm", "logW", "lse")},
-                _c(model.f_tran.hip_params()), _c(model.g_tran.hip_params()),
-                _c(model.q1_inv_tran.hip_params()), _c(self.f.get_sigma()), _c(self.g.get_sigma()),
-                _c(self.q1_inv.get_sigma()), _c(self.BSim_q2.get_sigma()), _c(bmu2), _c(minit),
-                _c(self.BSim_q_init.get_sigma()), _c(imean), _c(isig), obs_TB, eps_b, u_b, sel_in)
-        return bs
+        # one opaque autograd node: psvo_bsim_forward / psvo_bsim_backward
+        score, bwX, flp, glp, Omega, sel = BsimFunction.apply(
+            self._desc(M), obs_TB, eps_b, u_b, sel_in, filt["Fm"], filt["logW"], filt["lse"],
+            *model.f_tran.hip_params(), *model.g_tran.hip_params(), *model.q1_inv_tran.hip_params(),
+            self.f.get_sigma(), self.g.get_sigma(), self.q1_inv.get_sigma(), self.BSim_q2.get_sigma(),
+            bmu2, minit, self.BSim_q_init.get_sigma(), imean, isig)
+        return {"score": score, "bwX": bwX, "flp": flp, "glp": glp, "Omega": Omega, "sel": sel}
 
     def BS_preprocess_obs(self, obs):
         """PSVO.py:205-216."""

@@ -58,3 +58,43 @@ class FilterFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(gq1) + tuple(gf) + tuple(gg) + (
             r["dsig_q1"], r["dsig_q2"] if two_q else None, None if boot else r["dsig_f"], r["dsig_g"],
             r["dmu2"] if two_q else None, r["dm0"], r["dsig0"], r["dfm0"], r["dfsig0"])
+
+
+class BsimFunction(torch.autograd.Function):
+    """psvo_bsim_forward / psvo_bsim_backward.
+
+    apply(desc, obs_TB, eps_b, u_b, sel_in, Fm, logW, lse,
+          fW1, fb1, fW2, fb2, gW1, gb1, gW2, gb2, qW1, qb1, qW2, qb2,
+          sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig)
+      -> score (B,N) [differentiable]; bwX (T,B,Dx,N), flp, glp, Omega (T,B,N), sel (T,B,N) [constants]
+    """
+
+    @staticmethod
+    def forward(ctx, desc, obs_TB, eps_b, u_b, sel_in, Fm, logW, lse, *t):
+        t = [_cf(v) for v in t]
+        f, g, q = tuple(t[0:4]), tuple(t[4:8]), tuple(t[8:12])
+        sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig = t[12:21]
+        filt = {"X": None, "Fm": _cf(Fm), "logW": _cf(logW), "lse": _cf(lse)}
+        need = any(ctx.needs_input_grad)
+        bs = ops.bsim_forward(desc, {**filt, "X": filt["Fm"]}, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit,
+                              sig_init, imean, isig, obs_TB, eps_b, u_b, sel_in, save=need)
+        ctx.desc, ctx.filt, ctx.bs = desc, filt, bs
+        ctx.saved = (f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b)
+        ctx.mark_non_differentiable(bs["bwX"], bs["flp"], bs["glp"], bs["Omega"], bs["sel"])
+        return bs["score"], bs["bwX"], bs["flp"], bs["glp"], bs["Omega"], bs["sel"]
+
+    @staticmethod
+    def backward(ctx, dscore, *_):
+        desc = ctx.desc
+        f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b = ctx.saved
+        r = ops.bsim_backward(desc, ctx.filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
+                              imean, isig, obs_TB, eps_b, ctx.bs, _cg(dscore))
+        Dx, Dy, H = desc.Dx, desc.Dy, desc.H
+        gf = ops.split_mlp_grad(r["gf"], Dx, H, Dx)
+        gg = ops.split_mlp_grad(r["gg"], Dx, H, Dy)
+        gq = ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
+        dFm = r["dFm_part"].sum(2)          # fold the per-workgroup partials
+        dlogW = r["dlogW_part"].sum(2)
+        return (None, None, None, None, None, dFm, dlogW, None) + tuple(gf) + tuple(gg) + tuple(gq) + (
+            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_part"].sum(2),
+            r["dminit_part"].sum(1), r["dsig_init"], r["dimean_part"].sum(1), r["disig"])

@@ -31,6 +31,7 @@ struct BsimArgs {
     float *bwX, *flp, *glp, *Omega;
     int32_t* sel_out;
     float* score;
+    float *lam2_all, *om_all, *mu1_all;  // optional saves for psvo_bsim_backward (may be null)
 };
 
 template <int DX>
@@ -212,6 +213,10 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         } else {
             float m1[DX], mu[DX];
             MQ::template eval<kRolled>(wqi, xp, m1);
+            if (a.mu1_all && valid && m == 0) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.mu1_all[(tb * DX + d) * N + n] = m1[d];
+            }
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
                 mu[d] = pc[d] * fmaf(pi1[d], m1[d], pi2[d] * bmu_c[d]);
@@ -332,7 +337,9 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
                     ls = ss;
                 }
             }
-            lam = fmaf(kLn2, lm + log2_fast(ls), kf);
+            const float lam2 = lm + log2_fast(ls);
+            lam = fmaf(kLn2, lam2, kf);
+            if (a.lam2_all && valid) a.lam2_all[(tb * N + n) * M + m] = lam2;
         } else {
             lam = diag_lp<DX>(x, im, i_isig, kiota);  // t = 0: q0 / f density at mu_0 (PSVO.py:169-175)
         }
@@ -351,6 +358,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         }
         const float total = __shfl(cdfv, gbase + M - 1);
         const float omega = om_raw - (omx + logf(total));
+        if (a.om_all && valid) a.om_all[(tb * N + n) * M + m] = omega;
         int sel;
         if (a.sel_in) {
             sel = sel_c;
@@ -453,6 +461,7 @@ extern "C" int psvo_bsim_forward(const psvo_desc* desc, const float* X, const fl
                                  const float* sig_init, const float* imean, const float* isig, const float* obs,
                                  const float* eps_b, const float* u_b, const int32_t* sel_in, float* bwX,
                                  float* flp, float* glp, float* Omega, int32_t* sel_out, float* score,
+                                 float* lam2_all, float* om_all, float* mu1_all,
                                  void* stream) {
     using namespace psvo;
     if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 ||
@@ -472,6 +481,7 @@ extern "C" int psvo_bsim_forward(const psvo_desc* desc, const float* X, const fl
     a.bmu2 = bmu2; a.minit = minit; a.sig_init = sig_init; a.imean = imean; a.isig = isig;
     a.obs = obs; a.eps_b = eps_b; a.u_b = u_b; a.sel_in = sel_in;
     a.bwX = bwX; a.flp = flp; a.glp = glp; a.Omega = Omega; a.sel_out = sel_out; a.score = score;
+    a.lam2_all = lam2_all; a.om_all = om_all; a.mu1_all = mu1_all;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {
         case 2: return bsim_dispatch_dy<2>(a, desc->Dy, desc->H, desc->M, s);

@@ -88,7 +88,7 @@ def filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, 
 
 
 def bsim_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
-                 imean, isig, obs, eps_b, u_b=None, sel_in=None):
+                 imean, isig, obs, eps_b, u_b=None, sel_in=None, save=False):
     """psvo_bsim_forward.  `filt` is the dict returned by filter_forward.
     Returns dict(bwX, flp, glp, Omega, sel, score)."""
     lib = _lib.load()
@@ -112,6 +112,10 @@ def bsim_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu
         "bwX": torch.empty(T, B, Dx, N, device=dev), "flp": torch.empty(T, B, N, device=dev),
         "glp": torch.empty(T, B, N, device=dev), "Omega": torch.empty(T, B, N, device=dev),
         "sel": torch.empty(T, B, N, device=dev, dtype=torch.int32), "score": torch.empty(B, N, device=dev),
+        "lam2": torch.empty(T, B, N, M, device=dev) if save else None,
+        "om": torch.empty(T, B, N, M, device=dev) if save else None,
+        # rows t = T-1 of mu1 are never written by the kernel (no predecessor step): keep them defined
+        "mu1": torch.zeros(T, B, Dx, N, device=dev) if save else None,
     }
     st = lib.psvo_bsim_forward(
         ctypes.byref(desc), _ptr(filt["X"]), _ptr(filt["Fm"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
@@ -119,7 +123,7 @@ def bsim_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu
         _ptr(sig_f), _ptr(sig_g), _ptr(sig_q1inv), _ptr(sig_bq2), _ptr(bmu2), _ptr(minit), _ptr(sig_init),
         _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(u_b), _ptr(sel_in),
         _ptr(out["bwX"]), _ptr(out["flp"]), _ptr(out["glp"]), _ptr(out["Omega"]), _ptr(out["sel"]),
-        _ptr(out["score"]), _stream())
+        _ptr(out["score"]), _ptr(out["lam2"]), _ptr(out["om"]), _ptr(out["mu1"]), _stream())
     _lib.check(st, "psvo_bsim_forward")
     return out
 
@@ -158,21 +162,17 @@ def bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=False):
     return (out, cs, gates) if save else out
 
 
-def mlp_wgrad(X, dOut, w, Din, H, Dout, grad=None):
+def mlp_wgrad(X, dOut, w, Din, H, Dout, grad=None, axis=2):
     """psvo_mlp_wgrad: rows X [S][Din][L], dOut [S][Dout][L] -> flat grad [dW1|db1|dW2|db2].
-    X / dOut are any contiguous tensors whose leading dims flatten to S and whose last dim(s)
-    flatten to L, e.g. (T,B,Din,N) or (T,B,Din,N,M)."""
+    X / dOut are contiguous tensors whose feature axis is `axis` (dims before it flatten to the
+    segments S, dims after it to the rows L of a segment), e.g. (T,B,Din,N) or (T,B,Din,N,M)."""
     lib = _lib.load()
     dev = X.device
-    if X.dim() < 3 or not X.is_contiguous() or not dOut.is_contiguous():
-        raise ValueError("mlp_wgrad wants contiguous [S..., D, L...] tensors")
-    # locate the feature axis: X has Din there, dOut has Dout
-    ax = None
-    for i in range(X.dim()):
-        if X.shape[i] == Din and dOut.shape[i] == Dout and X.shape[:i] == dOut.shape[:i] and X.shape[i + 1:] == dOut.shape[i + 1:]:
-            ax = i
-    if ax is None:
-        raise ValueError("mlp_wgrad: cannot match shapes %s / %s to Din=%d, Dout=%d" % (tuple(X.shape), tuple(dOut.shape), Din, Dout))
+    ax = axis
+    if (not X.is_contiguous() or not dOut.is_contiguous() or X.shape[ax] != Din or dOut.shape[ax] != Dout
+            or X.shape[:ax] != dOut.shape[:ax] or X.shape[ax + 1:] != dOut.shape[ax + 1:]):
+        raise ValueError("mlp_wgrad: bad row tensors %s / %s for Din=%d, Dout=%d, axis=%d"
+                         % (tuple(X.shape), tuple(dOut.shape), Din, Dout, ax))
     S = 1
     for v in X.shape[:ax]:
         S *= v
@@ -227,4 +227,43 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
     out["gq1"] = mlp_wgrad(filt["X"], out["dP"], q1, Dx, H, Dx)
     out["gf"] = None if desc.bootstrap else mlp_wgrad(filt["X"], out["dF"], f, Dx, H, Dx)
     out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy)
+    return out
+
+
+def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig,
+                  obs, eps_b, bs, dscore):
+    """psvo_bsim_backward + psvo_mlp_wgrad.  `bs` = bsim_forward(..., save=True) outputs."""
+    lib = _lib.load()
+    B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
+    dev = eps_b.device
+    fs = _mlp_struct(f, Dx, H, Dx, "f")
+    gs = _mlp_struct(g, Dx, H, Dy, "g")
+    qs = _mlp_struct(q1_inv, Dx, H, Dx, "q1_inv")
+    _chk(dscore, (B, N), "dscore")
+    for k, shp in (("lam2", (T, B, N, M)), ("om", (T, B, N, M)), ("mu1", (T, B, Dx, N)), ("bwX", (T, B, Dx, N))):
+        if bs.get(k) is None:
+            raise ValueError("bsim_backward needs bsim_forward(save=True) outputs (missing %s)" % k)
+        _chk(bs[k], shp, k)
+    nblk = lib.psvo_bsim_blocks(N, M)
+    z = lambda *s: torch.empty(*s, device=dev)
+    out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
+           "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N), "dbmu2_part": z(T, B, nblk, Dx),
+           "dminit_part": z(B, nblk, Dx), "dimean_part": z(B, nblk, Dx),
+           "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx)}
+    sacc = z(B, nblk, lib.psvo_bsim_acc_size(Dx, Dy))
+    st = lib.psvo_bsim_backward(
+        ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
+        ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs),
+        _ptr(sig_f), _ptr(sig_g), _ptr(sig_q1inv), _ptr(sig_bq2), _ptr(bmu2), _ptr(minit), _ptr(sig_init),
+        _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(bs["bwX"]), _ptr(bs["sel"]),
+        _ptr(bs["lam2"]), _ptr(bs["om"]), _ptr(bs["mu1"]), _ptr(dscore),
+        _ptr(out["xt"]), _ptr(out["dFt"]), _ptr(out["dGt"]), _ptr(out["dmu1"]),
+        _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(out["dbmu2_part"]), _ptr(out["dminit_part"]),
+        _ptr(out["dimean_part"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
+        _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(sacc), _stream())
+    _lib.check(st, "psvo_bsim_backward")
+    # weight gradients from rows: MLP_f / MLP_g on the sub-particles, MLP_q1inv on bwX[t+1]
+    out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx)
+    out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy)
+    out["gq1inv"] = mlp_wgrad(bs["bwX"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx)
     return out

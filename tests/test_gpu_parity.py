@@ -190,20 +190,24 @@ def _check_grads(model, P, rtol=2e-3):
     assert not bad, "gradient mismatch (name, max abs err, ref scale): %s" % bad
 
 
-GRAD_CASES = [c for c in CASES if c[0] != "PSVO"]
+GRAD_CASES = CASES
 
 
 @pytest.mark.parametrize("case", GRAD_CASES, ids=lambda c: "-".join(map(str, c)))
 def test_filter_gradients(built_lib, case):
-    """d log_ZSMC / d(all parameters) for SVO / AESMC / IWAE, teacher-forced ancestors."""
+    """d log_ZSMC / d(all parameters) for SVO / AESMC / IWAE / PSVO, teacher-forced indices."""
     obj = case[0]
     FLAGS, model, smc, obs, noise = _setup(*case, seed=5)
     _, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
     teacher = {"idx_f": ref0["idx_f"]} if ref0["idx_f"] is not None else {}
+    if obj == "PSVO":
+        teacher["idx_b"] = ref0["idx_b"]
     z_ref, P = _oracle_grads(model, FLAGS, obj, obs, noise, teacher)
     nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
     if "idx_f" in nz:
         nz.pop("u_f", None)
+    if "sel_b" in nz:
+        nz.pop("u_b", None)
     model.zero_grad()
     z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
     z.backward()
