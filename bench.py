@@ -1,21 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- particle-steps/s of the PSVO hot path on MI355X (driver contract: see README/DESIGN).
+"""bench.py -- particle-steps/s of the PSVO hot path on MI355X.
 
-A "step" is one full evaluation of the objective on one batch of synthetic Fitzhugh-Nagumo
-sequences that is already resident in HBM: observation encoder, hoisted proposal means, random
-draws, forward particle filter, backward simulation (the N x N term) and the ELBO reduction.
+A "step" is ONE TRAINING STEP of the objective on one batch of synthetic Fitzhugh-Nagumo sequences
+already resident in HBM: observation encoder, hoisted proposal means, random draws, forward
+particle filter, backward simulation (the N x N term), ELBO, the full hand-written reverse pass,
+the flat-gradient all-reduce (RCCL, N > 1) and the fused Adam update -- i.e. one
+`sess.run(train_op)` of the reference (src/trainer.py:147-151).  The forward-only rate (one
+`sess.run(log_ZSMC)`) is reported beside it.
+
 Workload = BASELINE.json's target configuration "C*": PSVO (the reference's backward-simulation
-objective, BASELINE "SVO"), batch=32 per GPU, T=200, N=128, Dx=2, M=16, H=32, Dh=32.
+objective, BASELINE "SVO"), batch = 32 sequences per GPU, T = 200, N = 128, Dx = 2, M = 16,
+H = 32, Dh = 32.
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; the batch of
-sequences is sharded (32 per rank, weak scaling), there is no data-path collective in a forward
-evaluation, and the timed region is bracketed by barrier + synchronize with MAX over ranks.
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; the batch of sequences
+is sharded (32 per rank: weak scaling) and the only collective is the gradient all-reduce.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -38,11 +41,16 @@ EXP_PEAK = 9.8e12            # transcendental quarter rate, exp/s
 
 
 def flop_model(Dx, Dy, N, M, H, E):
-    """Algorithmic flop per particle-step, SURVEY.md section 8(d)."""
+    """Algorithmic flop per particle-step of each native kernel (forward figures: SURVEY.md section 8(d);
+    backward figures: DESIGN.md section 5).  FMA = 2 flop, exp/log = 1."""
     mlp = lambda i, o: 2 * H * (i + o)
     f_filt = mlp(Dx, Dx) + mlp(Dx, Dy) + mlp(E, Dx) / N + 20 * Dx + 6 * Dy + 10
     f_bsim = 2 * mlp(Dx, Dx) + M * (mlp(Dx, Dx) + mlp(Dx, Dy)) + M * N * (3 * Dx + 4) + M * (14 * Dx + 6 * Dy + 12)
-    return f_filt, f_bsim, M * N
+    # reverse passes: MLP forward recompute + input-gradient pass (2x), second pair pass (5 Dx + 6 per pair)
+    f_filt_b = 2 * (mlp(Dx, Dx) + mlp(Dx, Dy)) + 40 * Dx + 12 * Dy + 20
+    f_bsim_b = 2 * mlp(Dx, Dx) + 2 * M * (mlp(Dx, Dx) + mlp(Dx, Dy)) + M * N * (5 * Dx + 6) + M * (20 * Dx + 8 * Dy + 20)
+    return {"psvo_filter_forward": f_filt, "psvo_bsim_forward": f_bsim,
+            "psvo_filter_backward": f_filt_b, "psvo_bsim_backward": f_bsim_b}, M * N
 
 
 def fhn_batch(B, T, seed, device):
@@ -87,25 +95,39 @@ def build_objective(wl, device, seed=0):
     return FLAGS, model, smc
 
 
-def cpu_baseline(wl, model, obs_cpu, sample_T, threads):
+def cpu_baseline(wl, P, obs_cpu, sample_T, threads, train):
     """Time the CPU oracle (op-for-op restatement of the reference's TF graph, including the
     materialised (M, N, N, B) tile) on the host cores, on the first `sample_T` time steps."""
     from oracle import psvo_oracle as O
     obj, B, T, N, Dx, Dy, M, H, Dh = wl
     torch.set_num_threads(threads)
-    P = O.params_to(model.export_reference_layout(torch.float32), torch.float32)
+    P = O.params_to(P, torch.float32)
     fl = dict(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, use_bootstrap=True, use_2_q=True,
               objective=obj)
-    o = O.OBJECTIVES[obj](P, fl)
     obs_s = obs_cpu[:, :sample_T].contiguous()
     noise = O.make_noise(fl, B, sample_T, seed=99, dtype=torch.float32)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        o.get_log_ZSMC(obs_s, noise)
-        dt = time.perf_counter() - t0
+    if train:
+        def req(x):
+            if torch.is_tensor(x):
+                x.requires_grad_(True)
+            elif isinstance(x, dict):
+                [req(v) for v in x.values()]
+            elif isinstance(x, (list, tuple)):
+                [req(v) for v in x]
+        req(P)
+    o = O.OBJECTIVES[obj](P, fl)
+    t0 = time.perf_counter()
+    if train:
+        z, _ = o.get_log_ZSMC(obs_s, noise)
+        z.backward()
+    else:
+        with torch.no_grad():
+            o.get_log_ZSMC(obs_s, noise)
+    dt = time.perf_counter() - t0
+    what = "training step (forward + torch autograd, no optimizer)" if train else "forward evaluation (no_grad)"
     return {"value": B * sample_T * N / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
-            "sample": "forward evaluation (no_grad, fp32) of the first %d of %d time steps of the same workload, "
-                      "PyTorch-CPU oracle, %.1f s" % (sample_T, T, dt)}
+            "sample": "%s in fp32 of the first %d of %d time steps of the same workload, PyTorch-CPU oracle "
+                      "(materialises the (M,N,N,B) tile like the reference's TF graph), %.1f s" % (what, sample_T, T, dt)}
 
 
 def main():
@@ -114,8 +136,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C*", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-T", type=int, default=200)
+    ap.add_argument("--cpu-sample-T", type=int, default=40)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
@@ -129,70 +152,92 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the PSVO hot path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+
+    from psvo_amd import dp, ops
+    from psvo_amd.optim import FlatParams, TFAdam
+    dp.init(backend="nccl", device=device)
+    dist = torch.distributed if world > 1 else None
 
     wl = WORKLOADS[args.workload]
     obj, B, T, N, Dx, Dy, M, H, Dh = wl
     FLAGS, model, smc = build_objective(wl, device, seed=0)
+    P_ref = model.export_reference_layout(torch.float32)     # snapshot for the CPU baseline
     smc.generator = torch.Generator(device=device).manual_seed(1234 + rank)
     hidden, obs = fhn_batch(B, T, seed=100 + rank, device=device)
+    flat = FlatParams(model)
+    dp.broadcast_(flat.flat)
+    opt = TFAdam(flat)
+    lr = 3e-3
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    kern = {"i": -1}
-    dominant = "psvo_bsim_forward" if obj == "PSVO" else "psvo_filter_forward"
+    # HIP events around every native launch, on the stream they are launched on (torch's current stream)
+    events = {}
+    rec = {"on": False}
 
-    # HIP events around the dominant kernel, on the stream it is launched on (torch's current stream)
-    from psvo_amd import ops
-    target = ops.bsim_forward if obj == "PSVO" else ops.filter_forward
-    name = target.__name__
+    def hook(name, phase):
+        if rec["on"]:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            events.setdefault(name, []).append(e)
+    ops.set_timing_hook(hook)
 
-    def timed(*a, **k):
-        i = kern["i"]
-        if i >= 0:
-            ev[i][0].record()
-        out = target(*a, **k)
-        if i >= 0:
-            ev[i][1].record()
-        return out
-    setattr(ops, name, timed)
-
-    def step():
-        with torch.no_grad():
-            z, log = smc.get_log_ZSMC(obs, hidden)
+    def train_step():
+        flat.zero_grad()
+        z, _ = smc.get_log_ZSMC(obs, hidden)
+        z.backward()
+        dp.all_reduce_sum_(flat.grad)
+        opt.step(lr, world_size=world)
         return z
+
+    def fwd_step():
+        with torch.no_grad():
+            z, _ = smc.get_log_ZSMC(obs, hidden)
+        return z
+
+    step = train_step if args.mode == "train" else fwd_step
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, steps, record):
+        sync()
+        rec["on"] = record
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            z = fn()
+        rec["on"] = False
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, z
+
     for _ in range(args.warmup):
         z = step()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        kern["i"] = i
-        z = step()
-    kern["i"] = -1
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    elbo = float(z)
+    elapsed, z = timed(step, args.steps, True)
+    elbo = float(z.detach())
+    other = None
+    if args.mode == "train":     # forward-only rate beside it (not `value`)
+        for _ in range(2):
+            fwd_step()
+        nf = max(5, args.steps // 2)
+        el_f, _ = timed(fwd_step, nf, False)
+        other = world * B * T * N * nf / el_f
 
     if rank == 0:
-        k_ms = sorted(a.elapsed_time(b) for a, b in ev)
-        k_avg = sum(k_ms) / len(k_ms)
-        E = Dy
-        f_filt, f_bsim, x_bsim = flop_model(Dx, Dy, N, M, H, E)
-        f_dom = f_bsim if obj == "PSVO" else f_filt
         units = B * T * N                                    # particle-steps one launch processes
+        kms = {}
+        for name, evs in events.items():
+            d = [evs[i].elapsed_time(evs[i + 1]) for i in range(0, len(evs) - 1, 2)]
+            kms[name] = (sum(d) / args.steps, len(d) / args.steps)   # ms per step (all calls), calls per step
+        flops, x_bsim = flop_model(Dx, Dy, N, M, H, Dy)
+        cand = {k: v for k, v in kms.items() if k in flops}
+        dominant = max(cand, key=lambda k: cand[k][0])
+        k_avg = cand[dominant][0] / max(1.0, cand[dominant][1])
+        f_dom = flops[dominant]
         achieved = units * f_dom / (k_avg * 1e-3) / 1e12
         value = world * units * args.steps / elapsed
         out = {
@@ -202,21 +247,22 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s on Fitzhugh-Nagumo, batch=%d/GPU, T=%d, N=%d, Dx=%d, M=%d, H=%d, Dh=%d"
                                    % (args.workload, obj, B, T, N, Dx, M, H, Dh),
-                       "mode": "objective evaluation (ELBO + smoothed trajectories), forward only",
+                       "mode": ("training step: forward + reverse pass + gradient all-reduce + Adam"
+                                if args.mode == "train" else "objective evaluation (ELBO + smoothed trajectories)"),
                        "global_batch": B * world, "parallelism": "dp%d (batch of sequences sharded)" % world,
-                       "elbo": elbo},
+                       "elbo": elbo, "forward_only_particle_steps_per_s": other,
+                       "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": dominant, "kernel_ms_avg": k_avg, "kernel_ms_median": k_ms[len(k_ms) // 2],
-                         "flop_per_particle_step": f_dom,
-                         "exp_frac": (units * x_bsim / (k_avg * 1e-3) / EXP_PEAK) if obj == "PSVO" else None,
-                         "note": "fp32 VALU + transcendental work, not GEMM-shaped: priced against the f32 peak "
-                                 "(f32-input MFMA dense peak == f32 vector peak = 157.3 TFLOP/s); the path is "
-                                 "serial in t, so it is latency-limited well before this ceiling"},
+                         "kernel": dominant, "kernel_ms_avg": k_avg, "flop_per_particle_step": f_dom,
+                         "exp_frac": (units * x_bsim / (k_avg * 1e-3) / EXP_PEAK) if "bsim" in dominant else None,
+                         "note": "fp32 VALU + transcendental work, not GEMM-shaped (K = Dx <= 4): priced against the "
+                                 "f32 peak (f32-input MFMA dense peak == f32 vector peak = 157.3 TFLOP/s); the path "
+                                 "is serial in t, so it is latency-limited well before this ceiling"},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, model.cpu(), obs.cpu(), min(args.cpu_sample_T, T),
-                                               min(args.cpu_threads, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(wl, P_ref, obs.cpu(), min(args.cpu_sample_T, T),
+                                               min(args.cpu_threads, os.cpu_count() or 1), args.mode == "train")
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

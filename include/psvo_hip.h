@@ -234,6 +234,21 @@ int psvo_bilstm_forward(int B, int T, int Din, int Dh, const float* x,
                         const float* W_fw, const float* b_fw, const float* W_bw, const float* b_bw,
                         float* out, float* cs, float* gates, void* stream);
 
+/* Back-propagation through time of psvo_bilstm_forward (needs its cs / gates saves).
+ *   dout (B,T,2Dh) = d loss / d out.  Outputs: dx_part (2,B,T,Din) per-direction input gradients
+ *   (sum over axis 0), dW_part (B,2,Din+Dh,4Dh) and db_part (B,2,4Dh) per-sequence weight-gradient
+ *   partials (sum over axis 0; index 0 = forward direction, 1 = backward). */
+int psvo_bilstm_backward(int B, int T, int Din, int Dh, const float* x,
+                         const float* W_fw, const float* W_bw,
+                         const float* out, const float* cs, const float* gates, const float* dout,
+                         float* dx_part, float* dW_part, float* db_part, void* stream);
+
+/* Fused Adam update of one flat fp32 parameter vector: tf.train.AdamOptimizer(lr).minimize(-log_ZSMC)
+ * of the reference (src/trainer.py:115-118), TF 1.12 epsilon-hat form.  `step` counts from 1;
+ * `grad_scale` multiplies the gradient first (-1/world_size for a summed all-reduce of d log_ZSMC). */
+int psvo_adam_step(float* params, const float* grads, float* m, float* v, long long n, float lr,
+                   float beta1, float beta2, float eps, long long step, float grad_scale, void* stream);
+
 /* Per-sequence ELBO reductions (no batch mean: the caller averages, so a batch shard can be
  * all-reduced).  filter: out[b] = sum_t lse[t,b] (SVO.compute_log_ZSMC, SVO.py:302-311);
  * bsim: out[b] = logsumexp_n score[b,n] - log N (PSVO.compute_log_ZSMC, PSVO.py:52-67). */

@@ -98,3 +98,23 @@ class BsimFunction(torch.autograd.Function):
         return (None, None, None, None, None, dFm, dlogW, None) + tuple(gf) + tuple(gg) + tuple(gq) + (
             r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_part"].sum(2),
             r["dminit_part"].sum(1), r["dsig_init"], r["dimean_part"].sum(1), r["disig"])
+
+
+class BiLSTMFunction(torch.autograd.Function):
+    """psvo_bilstm_forward / psvo_bilstm_backward: one bidirectional LSTMBlockCell layer."""
+
+    @staticmethod
+    def forward(ctx, x, W_fw, b_fw, W_bw, b_bw):
+        x, W_fw, b_fw, W_bw, b_bw = (_cf(v) for v in (x, W_fw, b_fw, W_bw, b_bw))
+        if any(ctx.needs_input_grad):
+            out, cs, gates = ops.bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=True)
+            ctx.saved = (x, W_fw, W_bw, out, cs, gates)
+        else:
+            out = ops.bilstm_forward(x, W_fw, b_fw, W_bw, b_bw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W_fw, W_bw, out, cs, gates = ctx.saved
+        dx, dWf, dbf, dWb, dbb = ops.bilstm_backward(x, W_fw, W_bw, out, cs, gates, _cg(dout))
+        return dx, dWf, dbf, dWb, dbb

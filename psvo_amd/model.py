@@ -53,12 +53,12 @@ class StackBiRNN(nn.Module):
 
     def forward(self, x_BTD):
         h = x_BTD
-        if h.is_cuda and not torch.is_grad_enabled():
-            # one persistent HIP launch per layer (psvo_bilstm_forward) instead of ~4 T launches
-            from . import ops
+        if h.is_cuda:
+            # one persistent HIP launch per layer and direction pair (psvo_bilstm_forward /
+            # psvo_bilstm_backward) instead of ~4 T launches of a per-step LSTM
+            from .autograd import BiLSTMFunction
             for fw, bw in zip(self.fw, self.bw):
-                c = lambda t: t.detach().float().contiguous()
-                h = ops.bilstm_forward(c(h), c(fw.kernel), c(fw.bias), c(bw.kernel), c(bw.bias))
+                h = BiLSTMFunction.apply(h, fw.kernel, fw.bias, bw.kernel, bw.bias)
             return h
         B = h.shape[0]
         for fw, bw in zip(self.fw, self.bw):

@@ -51,6 +51,21 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional instrumentation: bench.py installs a hook that records HIP events (on the stream the
+# kernels are launched on) right before and after each native launch.  None = no overhead.
+_HOOK = None
+
+
+def set_timing_hook(hook):
+    global _HOOK
+    _HOOK = hook
+
+
+def _mark(name, phase):
+    if _HOOK is not None:
+        _HOOK(name, phase)
+
+
 def filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
                    obs, eps, u=None, idx_in=None):
     """psvo_filter_forward.  Returns dict(X, Xanc, Fm, logW, idx, lse)."""
@@ -77,12 +92,14 @@ def filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, 
         "idx": torch.empty(T, B, N, device=dev, dtype=torch.int32), "lse": torch.empty(T, B, device=dev),
         "P1": None if desc.bootstrap else torch.empty(T, B, Dx, N, device=dev),
     }
+    _mark("psvo_filter_forward", 0)
     st = lib.psvo_filter_forward(
         ctypes.byref(desc), ctypes.byref(q1s), ctypes.byref(fs) if fs is not None else None, ctypes.byref(gs),
         _ptr(sig_q1), _ptr(sig_q2), _ptr(sig_f), _ptr(sig_g), _ptr(mu2), _ptr(m0), _ptr(sig0), _ptr(fm0),
         _ptr(fsig0), _ptr(obs), _ptr(eps), _ptr(u), _ptr(idx_in),
         _ptr(out["X"]), _ptr(out["Xanc"]), _ptr(out["Fm"]), _ptr(out["P1"]), _ptr(out["logW"]), _ptr(out["idx"]),
         _ptr(out["lse"]), _stream())
+    _mark("psvo_filter_forward", 1)
     _lib.check(st, "psvo_filter_forward")
     return out
 
@@ -117,6 +134,7 @@ def bsim_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu
         # rows t = T-1 of mu1 are never written by the kernel (no predecessor step): keep them defined
         "mu1": torch.zeros(T, B, Dx, N, device=dev) if save else None,
     }
+    _mark("psvo_bsim_forward", 0)
     st = lib.psvo_bsim_forward(
         ctypes.byref(desc), _ptr(filt["X"]), _ptr(filt["Fm"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
         ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs),
@@ -124,6 +142,7 @@ def bsim_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu
         _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(u_b), _ptr(sel_in),
         _ptr(out["bwX"]), _ptr(out["flp"]), _ptr(out["glp"]), _ptr(out["Omega"]), _ptr(out["sel"]),
         _ptr(out["score"]), _ptr(out["lam2"]), _ptr(out["om"]), _ptr(out["mu1"]), _stream())
+    _mark("psvo_bsim_forward", 1)
     _lib.check(st, "psvo_bsim_forward")
     return out
 
@@ -156,8 +175,10 @@ def bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=False):
     out = torch.empty(B, T, 2 * Dh, device=x.device)
     cs = torch.empty(2, B, T, Dh, device=x.device) if save else None
     gates = torch.empty(2, B, T, 4 * Dh, device=x.device) if save else None
+    _mark("psvo_bilstm_forward", 0)
     st = lib.psvo_bilstm_forward(B, T, Din, Dh, _ptr(x), _ptr(W_fw), _ptr(b_fw), _ptr(W_bw), _ptr(b_bw),
                                  _ptr(out), _ptr(cs), _ptr(gates), _stream())
+    _mark("psvo_bilstm_forward", 1)
     _lib.check(st, "psvo_bilstm_forward")
     return (out, cs, gates) if save else out
 
@@ -186,8 +207,10 @@ def mlp_wgrad(X, dOut, w, Din, H, Dout, grad=None, axis=2):
     acc = grad is not None
     if grad is None:
         grad = torch.empty(NP, device=dev)
+    _mark("psvo_mlp_wgrad", 0)
     st = lib.psvo_mlp_wgrad(S, L, Din, H, Dout, _ptr(X), _ptr(dOut), ctypes.byref(ws), _ptr(partial), _ptr(grad),
                             int(acc), _stream())
+    _mark("psvo_mlp_wgrad", 1)
     _lib.check(st, "psvo_mlp_wgrad")
     return grad
 
@@ -215,6 +238,7 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
            "dsig_q1": z(Dx), "dsig_q2": z(Dx), "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig0": z(Dx), "dfsig0": z(Dx)}
     sacc = z(B, lib.psvo_filter_acc_size(Dx, Dy))
     nparts = 1 if (dFm is not None or dlogW is not None) else 0
+    _mark("psvo_filter_backward", 0)
     st = lib.psvo_filter_backward(
         ctypes.byref(desc), ctypes.byref(q1s), ctypes.byref(fs) if fs is not None else None, ctypes.byref(gs),
         _ptr(sig_q1), _ptr(sig_q2), _ptr(sig_f), _ptr(sig_g), _ptr(mu2), _ptr(m0), _ptr(sig0), _ptr(fm0), _ptr(fsig0),
@@ -223,6 +247,7 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
         _ptr(out["dP"]), _ptr(out["dF"]), _ptr(out["dG"]), _ptr(out["dmu2"]), _ptr(out["dm0"]), _ptr(out["dfm0"]),
         _ptr(out["dsig_q1"]), _ptr(out["dsig_q2"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig0"]),
         _ptr(out["dfsig0"]), _ptr(sacc), _stream())
+    _mark("psvo_filter_backward", 1)
     _lib.check(st, "psvo_filter_backward")
     out["gq1"] = mlp_wgrad(filt["X"], out["dP"], q1, Dx, H, Dx)
     out["gf"] = None if desc.bootstrap else mlp_wgrad(filt["X"], out["dF"], f, Dx, H, Dx)
@@ -251,6 +276,7 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
            "dminit_part": z(B, nblk, Dx), "dimean_part": z(B, nblk, Dx),
            "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx)}
     sacc = z(B, nblk, lib.psvo_bsim_acc_size(Dx, Dy))
+    _mark("psvo_bsim_backward", 0)
     st = lib.psvo_bsim_backward(
         ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
         ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs),
@@ -261,9 +287,31 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
         _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(out["dbmu2_part"]), _ptr(out["dminit_part"]),
         _ptr(out["dimean_part"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
         _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(sacc), _stream())
+    _mark("psvo_bsim_backward", 1)
     _lib.check(st, "psvo_bsim_backward")
     # weight gradients from rows: MLP_f / MLP_g on the sub-particles, MLP_q1inv on bwX[t+1]
     out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx)
     out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy)
     out["gq1inv"] = mlp_wgrad(bs["bwX"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx)
     return out
+
+
+def bilstm_backward(x, W_fw, W_bw, out, cs, gates, dout):
+    """psvo_bilstm_backward -> (dx (B,T,Din), dW_fw, db_fw, dW_bw, db_bw)."""
+    lib = _lib.load()
+    B, T, Din = x.shape
+    Dh = W_fw.shape[1] // 4
+    _chk(dout, (B, T, 2 * Dh), "dout"); _chk(out, (B, T, 2 * Dh), "out")
+    _chk(cs, (2, B, T, Dh), "cs"); _chk(gates, (2, B, T, 4 * Dh), "gates")
+    dev = x.device
+    dx_part = torch.empty(2, B, T, Din, device=dev)
+    dW_part = torch.empty(B, 2, Din + Dh, 4 * Dh, device=dev)
+    db_part = torch.empty(B, 2, 4 * Dh, device=dev)
+    _mark("psvo_bilstm_backward", 0)
+    st = lib.psvo_bilstm_backward(B, T, Din, Dh, _ptr(x), _ptr(W_fw), _ptr(W_bw), _ptr(out), _ptr(cs), _ptr(gates),
+                                  _ptr(dout), _ptr(dx_part), _ptr(dW_part), _ptr(db_part), _stream())
+    _mark("psvo_bilstm_backward", 1)
+    _lib.check(st, "psvo_bilstm_backward")
+    dW = dW_part.sum(0)
+    db = db_part.sum(0)
+    return dx_part.sum(0), dW[0], db[0], dW[1], db[1]
