@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpsvo_hip.so")
+LIB_PATH = os.environ.get("PSVO_HIP_LIB") or os.path.join(_HERE, "csrc", "libpsvo_hip.so")
 
 PSVO_OK = 0
 PSVO_ERR_INVALID = -1

@@ -14,9 +14,9 @@
 //     d x~_m  -= dLambda_m sum_j p_mj (x~_m - F_j) / sigma_f^2
 //     d F_j   += sum_{chains, m} dLambda_m p_mj (x~_m - F_j) / sigma_f^2      (cross-chain reduction)
 //     d W^_j  += sum_{chains, m} dLambda_m p_mj                                (sums to 0 over j)
-// The cross-chain sums go to wave-private LDS accumulators (float LDS atomics; the 16 quads of a
-// wave start their walk over j at staggered offsets so one instruction touches 64 distinct j), are
-// folded in a fixed order at the end of the step and written as per-workgroup partials
+// The cross-chain sums are formed without atomics: each lane keeps the per-j partials of a chunk of
+// forward particles in registers, a 4-stage butterfly reduce-scatters them over the 16 quads of the
+// wave, the four waves are folded in a fixed order through LDS and written as per-workgroup partials
 // (T, B, nblk, ...) that psvo_filter_backward sums -- no global atomics, no cross-workgroup order.
 //
 // MLP weight gradients are left to psvo_mlp_wgrad: this kernel writes the rows x~ (xt) and the
@@ -74,7 +74,23 @@ __device__ __forceinline__ void read_slot(const float* p, float (&F)[DX], float&
     }
 }
 
-template <int DX, int DY, int H, int M>
+// One butterfly stage of the reduce-scatter over quads: the NN live entries are halved; the lane
+// keeps the half selected by its `bit` and adds the partner's (lane ^ mask) copy of that half.
+template <int CH, int NA, int NN>
+__device__ __forceinline__ void rs_stage(float (&A)[CH][NA], int bit, int mask) {
+#pragma unroll
+    for (int i = 0; i < NN / 2; ++i) {
+#pragma unroll
+        for (int d = 0; d < NA; ++d) {
+            const float lo = A[i][d], hi = A[i + NN / 2][d];
+            const float send = bit ? lo : hi;
+            const float keep = bit ? hi : lo;
+            A[i][d] = keep + __shfl_xor(send, mask);
+        }
+    }
+}
+
+template <int DX, int DY, int H, int M, int CH>
 __global__ void __launch_bounds__(256) bsim_bwd_kernel(const BsimBwdArgs a) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
@@ -96,7 +112,6 @@ __global__ void __launch_bounds__(256) bsim_bwd_kernel(const BsimBwdArgs a) {
     const bool valid = n_raw < N;
     const int n = valid ? n_raw : N - 1;
     const int gbase = lane - m;
-    const int qi = lane >> 2;  // quad index inside the wave
 
     float* wf = smem;
     float* wg = wf + MQ::kSize;
@@ -189,9 +204,7 @@ __global__ void __launch_bounds__(256) bsim_bwd_kernel(const BsimBwdArgs a) {
 #pragma unroll
     for (int d = 0; d < DX; ++d) dX[d] = 0.f;
 
-    const int nq = NP >> 2;
-    const int rs = nq >= 16 ? nq / 16 : 1;
-    const int joff = (qi * rs) % nq;  // staggered start of this quad's walk over j
+    const int nq = NP >> 2;  // forward-tile entries per quad lane
 
     for (int t = 0; t < T; ++t) {
         const size_t tb = (size_t)t * B + b;
@@ -231,7 +244,11 @@ __global__ void __launch_bounds__(256) bsim_bwd_kernel(const BsimBwdArgs a) {
         for (int d = 0; d < DX; ++d) dxt[d] = issel * dX[d];
 
         // ---- filter term: second pass over the forward tile -------------------------------------------------
+#ifdef PSVO_EXP_NOPAIR
+        if (false) {
+#else
         if (!first) {
+#endif
             const float lam2 = a.lam2_all[(tb * N + n) * M + m];
             float xq[4][DX], lq[4], dl[4], U[4][DX], V[4][DX];
 #pragma unroll
@@ -246,38 +263,57 @@ __global__ void __launch_bounds__(256) bsim_bwd_kernel(const BsimBwdArgs a) {
                 }
             }
             float* ja = jacc + wave * NA * NP;
-            int e = joff;
-            for (int it = 0; it < nq; ++it) {
-                const int j = e * 4 + q;
-                float F[DX], W;
-                read_slot<DX>(cur + j * PS, F, W);
-                float Aj[DX], Wj = 0.f;
+            // The walk over j is done in chunks of CH entries kept in registers; after each chunk the
+            // per-j partial sums (over this quad's four m) are reduce-scattered across the 16 quads
+            // of the wave (lane bits 2..5) with a 4-stage butterfly, so every lane ends up owning
+            // CH/16 fully reduced (j, d) sums which it stores -- no atomics, fixed summation order.
+            for (int c0 = 0; c0 < nq; c0 += CH) {
+                float A[CH][NA];
 #pragma unroll
-                for (int d = 0; d < DX; ++d) Aj[d] = 0.f;
+                for (int i2 = 0; i2 < CH; ++i2) {
+                    const int e = c0 + i2;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float u[DX], l = W;
+                    for (int d = 0; d < NA; ++d) A[i2][d] = 0.f;
+                    if (e < nq) {
+                        const int j = e * 4 + q;
+                        float F[DX], W;
+                        read_slot<DX>(cur + j * PS, F, W);
 #pragma unroll
-                    for (int d = 0; d < DX; ++d) {
-                        u[d] = xq[i][d] - F[d];
-                        l = fmaf(-u[d], u[d], l);
-                    }
-                    const float p = exp2_fast(l - lq[i]);
-                    const float c = dl[i] * p;
-                    Wj += c;
+                        for (int i = 0; i < 4; ++i) {
+                            float u[DX], l = W;
 #pragma unroll
-                    for (int d = 0; d < DX; ++d) {
-                        const float pu = p * u[d];
-                        U[i][d] += pu;
-                        V[i][d] = fmaf(pu, u[d], V[i][d]);
-                        Aj[d] = fmaf(c, u[d], Aj[d]);
+                            for (int d = 0; d < DX; ++d) {
+                                u[d] = xq[i][d] - F[d];
+                                l = fmaf(-u[d], u[d], l);
+                            }
+                            const float p = exp2_fast(l - lq[i]);
+                            const float c = dl[i] * p;
+                            A[i2][DX] += c;
+#pragma unroll
+                            for (int d = 0; d < DX; ++d) {
+                                const float pu = p * u[d];
+                                U[i][d] += pu;
+                                V[i][d] = fmaf(pu, u[d], V[i][d]);
+                                A[i2][d] = fmaf(c, u[d], A[i2][d]);
+                            }
+                        }
                     }
                 }
-                // wave-private accumulators: one instruction touches 64 distinct j (staggered quads)
+                rs_stage<CH, NA, CH>(A, (lane >> 2) & 1, 4);
+                rs_stage<CH, NA, CH / 2>(A, (lane >> 3) & 1, 8);
+                rs_stage<CH, NA, CH / 4>(A, (lane >> 4) & 1, 16);
+                rs_stage<CH, NA, CH / 8>(A, (lane >> 5) & 1, 32);
+                constexpr int R = CH / 16;
+                const int ebase = (((lane >> 2) & 1) * (CH / 2) + ((lane >> 3) & 1) * (CH / 4) +
+                                   ((lane >> 4) & 1) * (CH / 8) + ((lane >> 5) & 1) * (CH / 16));
 #pragma unroll
-                for (int d = 0; d < DX; ++d) atomicAdd(&ja[d * NP + j], Aj[d]);
-                atomicAdd(&ja[DX * NP + j], Wj);
-                e = (e + 1 == nq) ? 0 : e + 1;
+                for (int r = 0; r < R; ++r) {
+                    const int e = c0 + ebase + r;
+                    if (e < nq) {
+#pragma unroll
+                        for (int d = 0; d < NA; ++d) ja[d * NP + e * 4 + q] = A[r][d];
+                    }
+                }
             }
             // merge the quad's four j-slices; lane q keeps sub-particle i == q
             float Uo[DX], Vo[DX];
@@ -433,10 +469,7 @@ __global__ void __launch_bounds__(256) bsim_bwd_kernel(const BsimBwdArgs a) {
             for (int i = tid; i < NA * N; i += NTB) {
                 const int d = i / N, j = i - d * N;
                 float s = 0.f;
-                for (int w = 0; w < nwv; ++w) {
-                    s += jacc[(w * NA + d) * NP + j];
-                    jacc[(w * NA + d) * NP + j] = 0.f;
-                }
+                for (int w = 0; w < nwv; ++w) s += jacc[(w * NA + d) * NP + j];
                 if (d < DX) a.dFm_part[((tbm * nblk + blk) * DX + d) * N + j] = s * isf[d] / kappa;
                 else a.dlogW_part[(tbm * nblk + blk) * N + j] = s;
             }
@@ -475,12 +508,16 @@ __global__ void bsim_bwd_finalize(const float* __restrict__ sacc, int rows, cons
                                   const float* sig_bq2, float* dsig_f, float* dsig_g, float* dsig_q1inv,
                                   float* dsig_bq2, float* dsig_init, float* disig) {
     using AC = BAcc<DX, DY>;
+    __shared__ float tot[AC::kN];
     const int d = threadIdx.x;
-    auto total = [&](int k) {
-        float s = 0.f;
-        for (int r = 0; r < rows; ++r) s += sacc[(size_t)r * AC::kN + k];
-        return s;
-    };
+    for (int k = 0; k < AC::kN; ++k) {  // one wave: lanes stride over the (sequence, workgroup) rows
+        float v = 0.f;
+        for (int r = d; r < rows; r += 64) v += sacc[(size_t)r * AC::kN + k];
+        v = wave_sum(v);
+        if (d == 0) tot[k] = v;
+    }
+    __syncthreads();
+    auto total = [&](int k) { return tot[k]; };
     if (d < DX) {
         const float i1 = 1.f / sig_q1inv[d], i2 = 1.f / sig_bq2[d];
         const float c = 1.f / (i1 + i2);
@@ -520,7 +557,11 @@ static int launch_bsim_bwd(const BsimBwdArgs& a, const BsimBwdOut& o, hipStream_
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nwv * (DX + 1) * NP +
                                         2 * cpb * DX + 16);
     clear_hip_error();
-    hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
+    // chunk of forward-tile entries reduced in registers per butterfly: 32 when a quad lane walks >= 32
+    if (NP / 4 >= 32)
+        hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 32>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
+    else
+        hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 16>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
     hipLaunchKernelGGL((bsim_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc_part, a.B * nblk,
                        a.sig_q1inv, a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
     (void)AC::kN;

@@ -124,14 +124,15 @@ __global__ void __launch_bounds__(256) mlp_wgrad_kernel(const WgradArgs a, const
     }
 }
 
-// out[p] (+)= sum_blk partial[blk][p], fixed order
+// out[p] (+)= sum_blk partial[blk][p]: one wave per output element, lanes stride over the blocks
+// (fixed order, deterministic)
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int NP, float* __restrict__ out,
                                        int accumulate) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= NP) return;
+    const int p = blockIdx.x;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * NP + p];
-    out[p] = accumulate ? out[p] + s : s;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(size_t)b * NP + p];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[p] = accumulate ? out[p] + s : s;
 }
 
 template <int DIN, int DOUT>
@@ -139,7 +140,7 @@ static int launch_wgrad(const WgradArgs& a, int H, int nblk, float* out, int acc
     const int NP = DIN * H + H + H * DOUT + DOUT;
     clear_hip_error();
     hipLaunchKernelGGL((mlp_wgrad_kernel<DIN, DOUT>), dim3(nblk, H / kKC), dim3(256), 0, s, a, H);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((NP + 63) / 64), dim3(64), 0, s, a.partial, nblk, NP, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(NP), dim3(64), 0, s, a.partial, nblk, NP, out, accumulate);
     return launch_status();
 }
 
