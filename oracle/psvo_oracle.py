@@ -224,7 +224,10 @@ class OracleSVO:
         if log_W.shape[0] == 1:
             # the reference asserts sample_size == 1 here (SVO.py:259); identity is the
             # only consistent definition for K == 1 and is what the build defines.
-            return X, torch.zeros(log_W.shape[1:], dtype=torch.long)
+            idx0 = torch.zeros(log_W.shape[1:], dtype=torch.long)
+            if sample_size == ():                 # one class, one draw per chain: drop the class axis
+                return ([x[0] for x in X] if isinstance(X, list) else X[0]), idx0
+            return X, idx0.unsqueeze(0)
         if idx is None:
             idx = multinomial_idx(log_W, u)
         g = gather_particles if sample_size != () else gather_sub

@@ -196,3 +196,37 @@ class SSM(nn.Module):
             P["q1_inv"] = dist(self.q1_inv_dist)
             P["BSim_q2"] = dist(self.BSim_q2_dist)
         return P
+
+    def load_reference_layout(self, P):
+        """Inverse of export_reference_layout: copy variables given in the reference's (keras / TF)
+        layout into this model (checkpoint import; tests load golden-fixture parameters with it)."""
+        def put(dst, src):
+            with torch.no_grad():
+                dst.copy_(torch.as_tensor(src).to(dst.device, dst.dtype))
+
+        def dist(d, p):
+            tr = d.transformation
+            for (W, b), (Ws, bs) in zip(zip(tr.kernels, tr.biases), p["layers"]):
+                put(W, Ws); put(b, bs)
+            put(tr.mu_kernel, p["mu"][0]); put(tr.mu_bias, p["mu"][1])
+            put(d.sigma_con, p["sigma_raw"])
+            d.sigma_min = float(p["sigma_min"])
+
+        dist(self.q0_dist, P["q0"]); dist(self.q1_dist, P["q1"]); dist(self.g_dist, P["g"])
+        if self.use_2_q:
+            dist(self.q2_dist, P["q2"])
+        if not self.use_bootstrap:
+            dist(self.f_dist, P["f"])
+        if not (self.use_bootstrap and self.use_2_q):
+            put(self.X0_transformer_kernel, P["X0_transformer"][0]); put(self.X0_transformer_bias, P["X0_transformer"][1])
+        if self.bRNN is not None:
+            for nm, s in (("y_smoother", self.y_smoother), ("X0_smoother", self.X0_smoother)):
+                if s is None:
+                    continue
+                for L, f, b in zip(P["bRNN"][nm], s.fw, s.bw):
+                    put(f.kernel, L["fw"][0]); put(f.bias, L["fw"][1])
+                    put(b.kernel, L["bw"][0]); put(b.bias, L["bw"][1])
+        if self.PSVO or self.PSVOwR:
+            dist(self.Bsim_q_init_dist, P["BSim_q_init"]); dist(self.q1_inv_dist, P["q1_inv"])
+            dist(self.BSim_q2_dist, P["BSim_q2"])
+        return self

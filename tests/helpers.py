@@ -68,3 +68,15 @@ def run_oracle(model, FLAGS, objective, obs, noise, teacher=None):
     with torch.no_grad():
         z, log = o.get_log_ZSMC(obs.double().cpu(), nz)
     return z, log
+
+
+def fill_from_npz(prefix, x, npz):
+    """Replace every tensor of the nested structure `x` by the array stored under its path in `npz`
+    (the inverse of tests/golden/make_golden.flatten)."""
+    if torch.is_tensor(x):
+        return torch.as_tensor(npz[prefix])
+    if isinstance(x, dict):
+        return {k: fill_from_npz(prefix + "." + str(k), v, npz) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(fill_from_npz(prefix + "." + str(i), v, npz) for i, v in enumerate(x))
+    return x

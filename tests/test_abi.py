@@ -1,0 +1,62 @@
+"""The C-ABI library builds, loads without a GPU, and exports every symbol include/psvo_hip.h
+declares; argument validation returns status codes before anything touches a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "psvo_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(psvo_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported_and_bound(built_lib):
+    from psvo_amd import _lib
+    lib = ctypes.CDLL(built_lib)
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libpsvo_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "psvo_amd/_lib.py does not bind %s" % n
+    for n in _lib.SIGNATURES:
+        assert n in names, "%s is bound but not declared in include/psvo_hip.h" % n
+
+
+def test_version_and_status_strings(built_lib):
+    from psvo_amd import _lib
+    lib = _lib.load()
+    assert lib.psvo_abi_version() == 1
+    assert lib.psvo_status_string(0) == b"ok"
+    assert b"unsupported" in lib.psvo_status_string(_lib.PSVO_ERR_UNSUPPORTED)
+    assert lib.psvo_filter_acc_size(2, 1) == 21 and lib.psvo_bsim_acc_size(3, 2) == 23
+    assert lib.psvo_bsim_blocks(128, 16) == 8 and lib.psvo_bsim_blocks(8, 4) == 1
+    assert lib.psvo_mlp_wgrad_blocks(10) == 1 and lib.psvo_mlp_wgrad_blocks(10 ** 9) == 1024
+
+
+def test_invalid_arguments_are_rejected_without_a_device(built_lib):
+    from psvo_amd import _lib
+    lib = _lib.load()
+    d = _lib.psvo_desc()
+    d.B, d.T, d.N, d.M, d.Dx, d.Dy, d.H = 2, 4, 8, 4, 2, 1, 32
+    nul = [None] * 20
+    st = lib.psvo_filter_forward(ctypes.byref(d), None, None, None, *nul, None)
+    assert st == _lib.PSVO_ERR_INVALID
+    st = lib.psvo_elbo_filter(ctypes.byref(d), None, None, None)
+    assert st == _lib.PSVO_ERR_INVALID
+    with pytest.raises(ValueError):
+        _lib.check(_lib.PSVO_ERR_UNSUPPORTED, "x")
+    with pytest.raises(_lib.PsvoHipError):
+        _lib.check(_lib.PSVO_ERR_HIP, "x")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from psvo_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.PsvoHipError):
+        _lib.load()

@@ -1,0 +1,104 @@
+"""world_size-2 data-parallel path on CPU (gloo): sharding, the single flat gradient all-reduce,
+replica consistency.  The per-rank compute is the CPU oracle here (checker only -- the HIP path
+needs a GPU); what is under test is psvo_amd.dp / psvo_amd.optim.FlatParams."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import psvo_oracle as O
+
+
+def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except Exception as e:  # report instead of letting the parent wait for its timeout
+        import traceback
+        traceback.print_exc()
+        q.put((rank, "error: %r" % (e,)))
+
+
+def _worker_body(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from psvo_amd import dp
+    from psvo_amd.optim import FlatParams
+    r, w = dp.init(backend="gloo")
+    assert (r, w) == (rank, world) and dp.world_size() == world and dp.rank() == rank
+    torch.manual_seed(0)
+    fl = dict(Dx=2, Dy=1, n_particles=6, n_particles_for_BSim_proposal=4, use_bootstrap=True, use_2_q=True,
+              objective="AESMC", layers=[8])
+    B, T = 4, 5
+    _, obs = O.fhn_synthetic(B, T, seed=1)
+    obs = obs.float()
+    noise = O.make_noise(fl, B, T, seed=3, dtype=torch.float32)
+    with torch.no_grad():
+        _, log = O.OracleAESMC(O.make_params(fl, seed=0, dtype=torch.float32), fl).get_log_ZSMC(obs, noise)
+    idx = log["idx_f"]
+
+    # a tiny torch module carrying the oracle's parameters, flattened by FlatParams
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            P = O.make_params(fl, seed=0, dtype=torch.float32)
+            self.P = P
+            self.ps = torch.nn.ParameterList()
+            for k in ("q0", "q1", "q2", "g"):
+                for W, b in P[k]["layers"] + [P[k]["mu"]]:
+                    self.ps.append(torch.nn.Parameter(W)); self.ps.append(torch.nn.Parameter(b))
+
+        def params(self):
+            P, it = {}, iter(self.ps)
+            for k in ("q0", "q1", "q2", "g"):
+                layers = [(next(it), next(it)) for _ in self.P[k]["layers"]]
+                P[k] = {"layers": layers, "mu": (next(it), next(it)), "sigma_raw": self.P[k]["sigma_raw"],
+                        "sigma_min": self.P[k]["sigma_min"]}
+            return P
+    m = M()
+    flat = FlatParams(m)
+    assert flat.flat.dtype == torch.float32 and flat.numel == sum(p.numel() for p in m.ps)
+    dp.broadcast_(flat.flat)
+
+    def elbo(lo, hi):
+        nz = {"eps_f": noise["eps_f"][:, :, lo:hi], "idx_f": idx[:, :, lo:hi]}
+        z, _ = O.OracleAESMC(m.params(), fl).get_log_ZSMC(obs[lo:hi], nz)
+        return z
+    # sharded: each rank differentiates the mean over ITS sequences, one all-reduce, divide by world
+    lo, hi = dp.shard(B)
+    assert (lo, hi) == (rank * 2, rank * 2 + 2)
+    flat.zero_grad()
+    elbo(lo, hi).backward()
+    dp.all_reduce_sum_(flat.grad)
+    g_dp = flat.grad.clone() / world
+    # reference: the full batch on one process
+    flat.zero_grad()
+    elbo(0, B).backward()
+    g_full = flat.grad.clone()
+    ok = torch.allclose(g_dp, g_full, atol=1e-4, rtol=1e-3)
+    zs = dp.all_reduce_mean_scalar(elbo(lo, hi).detach())
+    ok = ok and abs(float(zs) - float(elbo(0, B))) < 1e-3
+    ok = ok and dp.replicas_in_sync(flat.flat)
+    if rank == 1:
+        flat.flat[0] += 1.0
+    ok = ok and not dp.replicas_in_sync(flat.flat)
+    try:
+        dp.shard(5)
+        ok = False
+    except ValueError:
+        pass
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_gradient_allreduce_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=240) for _ in procs)
+    [p.join(60) for p in procs]
+    assert res == {0: True, 1: True}

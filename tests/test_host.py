@@ -1,0 +1,127 @@
+"""CPU tests of the host-side mirror: flag registry, SSM inventory / sharing, encoder and k-step
+prediction against the oracle, data loading / generation, R-square, and the refusal to run the
+hot path without a GPU (no CPU fallback)."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import psvo_oracle as O
+from psvo_amd import flags as F
+from psvo_amd.model import SSM
+from tests import helpers as Hh
+
+
+def test_flag_defaults_match_reference_and_parser_forms():
+    fl = F.Flags()
+    assert (fl.Dx, fl.Dy, fl.n_particles, fl.batch_size, fl.lr, fl.epoch, fl.seed) == (2, 1, 16, 1, 3e-3, 200, 2)
+    assert fl.PSVO and not (fl.SVO or fl.AESMC or fl.IWAE or fl.PSVOwR)
+    assert fl.n_particles_for_BSim_proposal == 16 and fl.q1_layers == "32" and fl.use_bootstrap and fl.use_2_q
+    assert abs(fl.lr_reduce_factor - 2 ** -0.5) < 1e-12 and abs(fl.min_lr - 3e-4) < 1e-12
+    p = F.parse_flags(["--Dx=3", "--noPSVO", "--AESMC", "--lr", "0.01", "--use_2_q=false", "--q1_layers=64,64"])
+    assert (p.Dx, p.PSVO, p.AESMC, p.lr, p.use_2_q, p.q1_layers) == (3, False, True, 0.01, False, "64,64")
+    with pytest.raises(ValueError):
+        F.parse_flags(["--no_such_flag=1"])
+    with pytest.raises(ValueError):
+        F.Flags(bogus=1)
+
+
+def test_ssm_inventory_and_sharing():
+    m = SSM(Hh.make_flags("PSVO"))
+    assert m.f_dist is m.q1_dist and m.f_tran is m.q1_tran                  # use_bootstrap: f == q1
+    assert m.g_dist.sigma_init == m.f_sigma_init                            # g_sigma_init quirk (model.py:37)
+    assert m.BSim_q2_tran.Din == 64 and m.q2_tran.Din == 1 and m.q0_tran.Din == 1
+    assert not hasattr(m, "X0_transformer_kernel")
+    n_params = sum(p.numel() for p in m.parameters())
+    assert n_params == 22426                                                # 8 MLPs + 4 LSTM cells
+    m2 = SSM(Hh.make_flags("SVO", use_bootstrap=False))
+    assert m2.f_dist is not m2.q1_dist and m2.q2_tran.Din == 64 and m2.q0_tran.Din == 2
+    assert tuple(m2.X0_transformer_kernel.shape) == (128, 2)
+    with pytest.raises(ValueError):
+        SSM(Hh.make_flags("AESMC", q1_layers="32,32")).q1_tran.hip_params()
+    with pytest.raises(NotImplementedError):
+        SSM(Hh.make_flags("AESMC", poisson_emission=True))
+
+
+def test_export_import_roundtrip_and_sigma():
+    torch.manual_seed(0)
+    a = Hh.perturb_(SSM(Hh.make_flags("PSVO", use_bootstrap=False)))
+    b = SSM(Hh.make_flags("PSVO", use_bootstrap=False)).load_reference_layout(a.export_reference_layout())
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+    P = a.export_reference_layout(torch.float64)
+    assert torch.allclose(a.q1_dist.get_sigma().double(), O.get_sigma(P["q1"]), atol=1e-6)
+
+
+def test_encoder_and_kstep_prediction_match_oracle_on_cpu():
+    torch.manual_seed(1)
+    FLAGS = Hh.make_flags("SVO", n_particles=6, y_smoother_Dhs="8,4", X0_smoother_Dhs="8")
+    m = Hh.perturb_(SSM(FLAGS))
+    P = m.export_reference_layout(torch.float64)
+    x = torch.randn(3, 9, 1)
+    ref = O.stack_bidirectional_rnn(x.double(), P["bRNN"]["y_smoother"])
+    assert torch.allclose(m.y_smoother(x).double(), ref, atol=1e-5)
+    from psvo_amd.SMC.SVO import SVO
+    smc = SVO(m, FLAGS)
+    o = O.OracleSVO(P, Hh.oracle_flags(FLAGS, "SVO"))
+    Xs = torch.randn(3, 9, 6, 2)
+    yh, y = smc.n_step_prediction(4, Xs, x)
+    yh_ref, y_ref = o.n_step_prediction(4, Xs.double(), x.double())
+    assert len(yh) == 5 and [tuple(v.shape) for v in yh] == [(3, 9 - k, 1) for k in range(5)]
+    for a_, b_ in zip(yh, yh_ref):
+        assert torch.allclose(a_.double(), b_, atol=1e-5)
+    assert torch.allclose(smc.get_nextX(Xs[:, :, 0]).double(), o.get_nextX(Xs[:, :, 0].double()), atol=1e-5)
+
+
+def test_r_square_matches_oracle_restatement():
+    from psvo_amd.trainer import trainer
+    g = np.random.RandomState(0)
+    y = [g.randn(12, 10 - k, 1) for k in range(3)]
+    yh = [v + 0.1 * g.randn(*v.shape) for v in y]
+    r = trainer.evaluate_R_square(None, yh, y)
+    ref = O.evaluate_R_square([torch.tensor(v) for v in yh], [torch.tensor(v) for v in y])
+    assert np.allclose(r, ref.numpy(), atol=1e-12) and (r > 0.9).all()
+
+
+def test_data_loader_formats(tmp_path):
+    from psvo_amd.utils.data_loader import load_data
+    d = {"Ytrain": np.zeros((6, 5)), "Yvalid": np.ones((2, 5)), "Ytest": np.ones((3, 5)), "Xtrue": np.zeros((9, 5, 2))}
+    p = tmp_path / "datadict"
+    pickle.dump(d, open(p, "wb"))
+    ht, hs, ot, os_ = load_data(str(p), 2, False, False)
+    assert ot.shape == (6, 5, 1) and os_.shape == (3, 5, 1) and ht.shape == (6, 5, 2) and hs.shape == (3, 5, 2)
+    pickle.dump({"Ytrain": np.zeros((4, 5, 1)), "Yvalid": np.zeros((2, 5, 1))}, open(p, "wb"))
+    ht, hs, ot, os_ = load_data(str(p), 3, False, False)
+    assert ht.shape == (4, 5, 3) and not ht.any()
+    with pytest.raises(ValueError):
+        load_data(str(p), 3, False, True)
+    pickle.dump({"Ytrain": np.zeros((4, 5, 1))}, open(p, "wb"))
+    with pytest.raises(ValueError):
+        load_data(str(p), 3, False, False)
+
+
+def test_data_generator_shapes_and_dynamics():
+    from psvo_amd.utils.data_generator import generate_dataset
+    np.random.seed(0)
+    ht, hs, ot, os_ = generate_dataset(3, 2, 20, model="fhn", Dy=1)
+    assert ht.shape == (3, 20, 2) and os_.shape == (2, 20, 1)
+    assert np.abs(ot[:, :, 0] - ht[:, :, 0]).std() < 0.2 and np.abs(ht).max() < 5
+    # one FHN step agrees with the oracle's RK4 restatement
+    hid, _ = O.fhn_synthetic(4, 3, seed=2)
+    from psvo_amd.utils.data_generator import _fhn_step
+    nxt = np.stack([_fhn_step(h.numpy(), (1.0, 0.95, 0.05, 1.0, 0.15)) for h in hid[:, 0]])
+    assert np.allclose(nxt, hid[:, 1].numpy(), atol=1e-5)
+    with pytest.raises(ValueError):
+        generate_dataset(1, 1, 5, model="nope")
+
+
+def test_hot_path_refuses_to_run_without_gpu():
+    """no CPU fallback: CPU tensors are rejected by the op wrappers"""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from psvo_amd.SMC.AESMC import AESMC
+    FLAGS = Hh.make_flags("AESMC", n_particles=8)
+    smc = AESMC(SSM(FLAGS), FLAGS)
+    with pytest.raises((ValueError, RuntimeError)):
+        smc.get_log_ZSMC(torch.zeros(2, 5, 1), None)

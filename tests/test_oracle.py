@@ -1,0 +1,181 @@
+"""CPU tests of the oracle itself: known-answer tests with analytic answers, a finite-difference
+check of its autograd, and the committed golden fixtures (regression pin).  The reference has no
+tests or fixtures for this path (parity unpinned at the TFP boundary), so these KATs are what pins
+the restatement's arithmetic."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import psvo_oracle as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden as MG  # noqa: E402
+
+
+def _flags(obj, **kw):
+    fl = dict(Dx=2, Dy=1, n_particles=8, n_particles_for_BSim_proposal=4, use_bootstrap=True, use_2_q=True,
+              objective=obj, layers=[8], y_smoother_Dhs=[4], X0_smoother_Dhs=[4])
+    fl.update(kw)
+    return fl
+
+
+def test_logsumexp_and_multinomial_unit_vectors():
+    logW = torch.log(torch.tensor([[0.1], [0.2], [0.3], [0.4]], dtype=torch.float64))
+    assert abs(float(O.logsumexp(logW, 0)) - 0.0) < 1e-12
+    # cdf = [.1, .3, .6, 1.0] (times a common factor): idx = #{cdf <= u}
+    u = torch.tensor([[0.05], [0.11], [0.29], [0.31], [0.59], [0.61], [0.999]], dtype=torch.float64)
+    idx = O.multinomial_idx(logW, u)
+    assert idx.flatten().tolist() == [0, 1, 1, 2, 2, 3, 3]
+    # sub-particle form: classes on axis 0, one draw per batch element
+    lw = torch.log(torch.tensor([[0.5, 0.1], [0.5, 0.9]], dtype=torch.float64))
+    assert O.multinomial_idx(lw, torch.tensor([0.49, 0.2], dtype=torch.float64)).tolist() == [0, 1]
+
+
+def test_diag_log_prob_matches_scipy():
+    from scipy.stats import multivariate_normal
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 3, generator=g, dtype=torch.float64)
+    mu = torch.randn(5, 3, generator=g, dtype=torch.float64)
+    s = torch.rand(3, generator=g, dtype=torch.float64) + 0.5
+    lp = O.diag_log_prob(x, mu, s)
+    for i in range(5):
+        ref = multivariate_normal(mu[i].numpy(), np.diag(s.numpy() ** 2)).logpdf(x[i].numpy())
+        assert abs(float(lp[i]) - ref) < 1e-10
+
+
+def test_bootstrap_without_2q_weights_are_emission_only():
+    """use_bootstrap and not use_2_q: f_t - q_t == 0 so log_W_t = g_t - log N (t >= 1) exactly
+    (SURVEY.md section 8c KAT)."""
+    fl = _flags("AESMC", use_2_q=False)
+    P = O.make_params(fl, seed=1, bias_scale=0.3)
+    _, obs = O.fhn_synthetic(2, 6, seed=0)
+    noise = O.make_noise(fl, 2, 6, seed=2)
+    o = O.OracleAESMC(P, fl)
+    _, log = o.get_log_ZSMC(obs, noise)
+    for t in range(1, 6):
+        g = o.g.log_prob(log["X_prevs"][t], obs[:, t])
+        assert torch.allclose(log["log_Ws"][t], g - math.log(8.0), atol=1e-12)
+
+
+def test_iwae_particle_permutation_invariance():
+    fl = _flags("IWAE")
+    P = O.make_params(fl, seed=3, bias_scale=0.3)
+    _, obs = O.fhn_synthetic(2, 5, seed=1)
+    noise = O.make_noise(fl, 2, 5, seed=4)
+    z1, _ = O.OracleIWAE(P, fl).get_log_ZSMC(obs, noise)
+    perm = torch.randperm(8, generator=torch.Generator().manual_seed(0))
+    noise2 = {"eps_f": noise["eps_f"][:, perm], "u_f": noise["u_f"][:, perm]}
+    z2, _ = O.OracleIWAE(P, fl).get_log_ZSMC(obs, noise2)
+    assert abs(float(z1) - float(z2)) < 1e-10
+
+
+def test_single_subparticle_gives_omega_equal_q():
+    """M = 1: normalised omega == 0 and Omega == q (+ log 1)."""
+    fl = _flags("PSVO", n_particles_for_BSim_proposal=1)
+    P = O.make_params(fl, seed=5, bias_scale=0.3)
+    _, obs = O.fhn_synthetic(2, 5, seed=2)
+    noise = O.make_noise(fl, 2, 5, seed=6)
+    o = O.OraclePSVO(P, fl)
+    _, log = o.get_log_ZSMC(obs, noise)
+    # recompute q of the single proposal at t = T-1 and compare with Omega
+    _, enc = o.BS_preprocess_obs(obs)
+    x, q = o.BSim_q_init.sample_and_log_prob(enc[-1], noise["eps_b"][4])
+    assert torch.allclose(log["bw_log_Omegas"][4], q[0], atol=1e-12)
+    assert torch.allclose(log["bw_Xs"][4], x[0], atol=1e-12)
+
+
+def _kalman_loglik(A, C, sf2, sg2, m0, P0, ys):
+    m, Pm, ll = m0, P0, 0.0
+    for t, y in enumerate(ys):
+        if t > 0:
+            m, Pm = A @ m, A @ Pm @ A.T + sf2
+        S = C @ Pm @ C.T + sg2
+        r = y - C @ m
+        ll += -0.5 * (r @ np.linalg.solve(S, r) + np.log(np.linalg.det(2 * np.pi * S)))
+        K = Pm @ C.T @ np.linalg.inv(S)
+        m, Pm = m + K @ r, (np.eye(len(m)) - K @ C) @ Pm
+    return ll
+
+
+def test_linear_gaussian_ssm_matches_kalman_likelihood():
+    """With zero hidden layers the MLPs are linear: bootstrap / no-2q AESMC is a bootstrap particle
+    filter of a linear-Gaussian SSM whose exact log-likelihood the Kalman filter gives; the SMC
+    estimate converges to it as N grows (SURVEY.md section 8c KAT)."""
+    Dx, Dy, T, B, N = 2, 1, 6, 2, 6000
+    fl = _flags("AESMC", Dx=Dx, Dy=Dy, n_particles=N, use_2_q=False, layers=[])
+    P = O.make_params(fl, seed=9, bias_scale=0.0)
+    g = torch.Generator().manual_seed(1)
+    A = torch.tensor([[0.9, 0.2], [-0.1, 0.8]], dtype=torch.float64)
+    C = torch.tensor([[1.0], [0.5]], dtype=torch.float64)            # (Dx, Dy) keras kernel of g
+    P["q1"]["mu"] = (A.t().contiguous(), torch.zeros(2, dtype=torch.float64))   # x W = A x
+    P["g"]["mu"] = (C, torch.zeros(1, dtype=torch.float64))
+    P["q0"]["mu"] = (A.t().contiguous(), torch.zeros(2, dtype=torch.float64))   # proposal == prior at t = 0
+    for k in ("q0", "q1", "g"):
+        P[k]["sigma_raw"] = torch.full_like(P[k]["sigma_raw"], 0.3)
+        P[k]["sigma_min"] = 0.7
+    sig = max(math.log1p(math.exp(0.3)), 0.7)                         # max(softplus(raw), sigma_min)
+    obs = torch.randn(B, T, Dy, generator=g, dtype=torch.float64)
+    noise = O.make_noise(fl, B, T, seed=5)
+    z, _ = O.OracleAESMC(P, fl).get_log_ZSMC(obs, noise)
+    W0, b0 = P["X0_transformer"]
+    ll = 0.0
+    for b in range(B):
+        z0 = (obs[b, 0] @ W0 + b0).numpy()
+        ll += _kalman_loglik(A.numpy(), C.t().numpy(), sig ** 2 * np.eye(2), sig ** 2 * np.eye(1),
+                             A.numpy() @ z0, sig ** 2 * np.eye(2), obs[b].numpy())
+    assert abs(float(z) - ll / B) < 0.05, (float(z), ll / B)
+
+
+def test_oracle_autograd_matches_finite_differences():
+    """teacher-forced indices make log_ZSMC a smooth function of the parameters"""
+    fl = _flags("PSVO", n_particles=5, n_particles_for_BSim_proposal=3)
+    P = O.make_params(fl, seed=2, bias_scale=0.3)
+    for k in P:
+        if isinstance(P[k], dict) and "sigma_raw" in P[k]:
+            P[k]["sigma_raw"] = torch.full_like(P[k]["sigma_raw"], 1.0)
+            P[k]["sigma_min"] = 0.2
+    _, obs = O.fhn_synthetic(2, 4, seed=3)
+    noise = O.make_noise(fl, 2, 4, seed=8)
+    with torch.no_grad():
+        _, log = O.OraclePSVO(P, fl).get_log_ZSMC(obs, noise)
+    teacher = {**noise, "idx_f": log["idx_f"], "idx_b": log["idx_b"]}
+    targets = [P["q1"]["layers"][0][0], P["g"]["mu"][1], P["q1_inv"]["sigma_raw"], P["BSim_q2"]["mu"][0],
+               P["bRNN"]["y_smoother"][0]["fw"][0]]
+    for t in targets:
+        t.requires_grad_(True)
+    z, _ = O.OraclePSVO(P, fl).get_log_ZSMC(obs, teacher)
+    grads = torch.autograd.grad(z, targets)
+    for t, g in zip(targets, grads):
+        flat = t.detach().view(-1)
+        for k in (0, flat.numel() // 2):
+            old = float(flat[k])
+            with torch.no_grad():
+                flat[k] = old + 1e-6
+                zp, _ = O.OraclePSVO(P, fl).get_log_ZSMC(obs, teacher)
+                flat[k] = old - 1e-6
+                zm, _ = O.OraclePSVO(P, fl).get_log_ZSMC(obs, teacher)
+                flat[k] = old
+            fd = (float(zp) - float(zm)) / 2e-6
+            assert abs(fd - float(g.view(-1)[k])) < 1e-5 * max(1.0, abs(fd)), (fd, float(g.view(-1)[k]))
+
+
+@pytest.mark.parametrize("name", sorted(MG.CASES))
+def test_golden_fixture_regression(name):
+    """the committed vectors are reproduced bit-for-bit-ish by the current oracle"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")
+    ref = np.load(path)
+    fl, P, obs, noise = MG.build(name)
+    z, log = MG.run(fl, P, obs, noise)
+    assert abs(float(z) - float(ref["log_ZSMC"])) < 1e-10
+    for k in ("Xs", "log_Ws", "bw_Xs", "bw_log_Omegas"):
+        if "out." + k in ref.files:
+            assert np.allclose(log[k].detach().numpy(), ref["out." + k], atol=1e-10)
+    for k in ("idx_f", "idx_b"):
+        if "out." + k in ref.files:
+            assert (log[k].numpy() == ref["out." + k]).all()
+    g = P["q1"]["layers"][0][0].grad
+    assert np.allclose(g.numpy(), ref["grad.q1.layers.0.0"], atol=1e-9)
