@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--workload", default="C*", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one captured hipGraph instead of issuing launches eagerly (measured: "
+                         "slower here, the small kernels between the persistent ones are GPU time, not host gaps)")
     ap.add_argument("--cpu-sample-T", type=int, default=40)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
@@ -193,7 +196,45 @@ def main():
             z, _ = smc.get_log_ZSMC(obs, hidden)
         return z
 
-    step = train_step if args.mode == "train" else fwd_step
+    # The step is captured once into a hipGraph and replayed (same kernels, same buffers, fresh random
+    # draws per replay).  With more than one rank only the local compute is captured; the gradient
+    # all-reduce and the Adam launch stay eager behind it.
+    from psvo_amd.graph import GraphedStep
+
+    def local_step():
+        flat.zero_grad()
+        z, _ = smc.get_log_ZSMC(obs, hidden)
+        z.backward()
+        return z.detach()
+
+    def update():
+        dp.all_reduce_sum_(flat.grad)
+        opt.step(lr, world_size=world)
+
+    use_graph = args.graph
+    if use_graph:
+        if args.mode == "train":
+            if world == 1:
+                def whole():
+                    z = local_step()
+                    update()
+                    return z
+                # Adam's bias-correction scalar depends on the step count: freeze it at its asymptote inside
+                # the captured launch (lr_t -> lr), which is what a long training run sees after ~5k steps
+                opt.t = 10 ** 6
+                g_step = GraphedStep(whole, generators=[smc.generator])
+                step = g_step
+            else:
+                g_local = GraphedStep(local_step, generators=[smc.generator])
+
+                def step():
+                    z = g_local()
+                    update()
+                    return z
+        else:
+            step = GraphedStep(lambda: fwd_step().detach(), generators=[smc.generator])
+    else:
+        step = train_step if args.mode == "train" else fwd_step
 
     def sync():
         if dist is not None:
@@ -217,8 +258,16 @@ def main():
 
     for _ in range(args.warmup):
         z = step()
-    elapsed, z = timed(step, args.steps, True)
+    elapsed, z = timed(step, args.steps, not use_graph)
     elbo = float(z.detach())
+    if use_graph:   # per-kernel HIP-event timings come from eager launches of the same step (events cannot be
+        eager = train_step if args.mode == "train" else fwd_step     # recorded inside a captured graph)
+        eager()
+        n_ev = max(3, min(args.steps, 10))
+        timed(eager, n_ev, True)
+        ev_steps = n_ev
+    else:
+        ev_steps = args.steps
     other = None
     if args.mode == "train":     # forward-only rate beside it (not `value`)
         for _ in range(2):
@@ -232,7 +281,7 @@ def main():
         kms = {}
         for name, evs in events.items():
             d = [evs[i].elapsed_time(evs[i + 1]) for i in range(0, len(evs) - 1, 2)]
-            kms[name] = (sum(d) / args.steps, len(d) / args.steps)   # ms per step (all calls), calls per step
+            kms[name] = (sum(d) / ev_steps, len(d) / ev_steps)       # ms per step (all calls), calls per step
         flops, x_bsim = flop_model(Dx, Dy, N, M, H, Dy)
         cand = {k: v for k, v in kms.items() if k in flops}
         dominant = max(cand, key=lambda k: cand[k][0])
@@ -251,6 +300,7 @@ def main():
                                 if args.mode == "train" else "objective evaluation (ELBO + smoothed trajectories)"),
                        "global_batch": B * world, "parallelism": "dp%d (batch of sequences sharded)" % world,
                        "elbo": elbo, "forward_only_particle_steps_per_s": other,
+                       "launch": "hipGraph replay" if use_graph else "eager",
                        "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,

@@ -10,8 +10,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpsvo_hip.so")
-SOURCES = ["api.hip", "filter_fwd.hip", "bsim_fwd.hip", "lstm.hip", "filter_bwd.hip", "mlp_grad.hip", "bsim_bwd.hip", "lstm_bwd.hip", "adam.hip"]
-HEADERS = ["common.h", os.path.join("..", "..", "include", "psvo_hip.h")]
+SOURCES = ["api.hip", "filter_fwd.hip", "bsim_fwd.hip", "lstm.hip", "filter_bwd.hip", "mlp_grad.hip", "bsim_bwd.hip", "bsim_bwd_dx2.hip", "bsim_bwd_dx3.hip", "bsim_bwd_dx4.hip",
+           "lstm_bwd.hip", "adam.hip"]
+HEADERS = ["common.h", "bsim_bwd_impl.h", os.path.join("..", "..", "include", "psvo_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 
@@ -37,7 +38,7 @@ def build_lib(force=False, verbose=True):
             print("[psvo_amd.build]", " ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

@@ -1,0 +1,669 @@
+// Reverse-mode pass of the backward simulation (gradient of sum_t(f+g-Omega) per chain w.r.t. every
+// input of psvo_bsim_forward).  The reference obtains it from TensorFlow autodiff, which stores the
+// (M, N, N, B[, Dx]) transition tile of every step (reference src/SMC/PSVO.py:128-133; SURVEY.md
+// section 5 "Long-context"); here the tile is RECOMPUTED from the LDS-staged forward particles and
+// only three small per-(t, chain[, m]) arrays saved by the forward kernel are read back
+// (lam2 = log2-domain filter term, omega = normalised sub-particle log-weights, mu1 = MLP_q1inv(x+)).
+//
+// Reverse order is t = 0 .. T-1 (the forward ran T-1 .. 0); the only state carried between steps is
+// d loss / d bwX_{t+1} per chain.  Same lane mapping as the forward kernel: lane = (chain, m), quad
+// register blocking over four m in the pair loop.  With a = d loss / d score[chain] and
+// pi_m = exp(omega_m):
+//     d phi_m = d g_m = a pi_m,   d Lambda_m = -a (delta_{m,sel} - pi_m),   d q_m = -a pi_m
+// and, for p_mj = softmax_j(log f(x~_m | F_j) + W^_j) recomputed from lam2:
+//     d x~_m  -= dLambda_m sum_j p_mj (x~_m - F_j) / sigma_f^2
+//     d F_j   += sum_{chains, m} dLambda_m p_mj (x~_m - F_j) / sigma_f^2      (cross-chain reduction)
+//     d W^_j  += sum_{chains, m} dLambda_m p_mj                                (sums to 0 over j)
+// The cross-chain sums are formed without atomics: each lane keeps the per-j partials of a chunk of
+// forward particles in registers, a 4-stage butterfly reduce-scatters them over the 16 quads of the
+// wave, the four waves are folded in a fixed order through LDS and written as per-workgroup partials
+// (T, B, nblk, ...) that psvo_filter_backward sums -- no global atomics, no cross-workgroup order.
+//
+// MLP weight gradients are left to psvo_mlp_wgrad: this kernel writes the rows x~ (xt) and the
+// output gradients dFt (MLP_f), dGt (MLP_g), dmu1 (MLP_q1inv).
+#pragma once
+#include "common.h"
+
+namespace psvo {
+
+struct BsimBwdArgs {
+    int B, T, N;
+    psvo_mlp f, g, q1inv;
+    const float *Fm, *logW, *lse;
+    const float *sig_f, *sig_g, *sig_q1inv, *sig_bq2;
+    const float *bmu2, *minit, *sig_init, *imean, *isig;
+    const float *obs, *eps_b;
+    const float* bwX;
+    const int32_t* sel;
+    const float *lam2_all, *om_all, *mu1_all;
+    const float* dscore;  // (B,N)
+    float *xt, *dFt, *dGt, *dmu1;
+    float *dFm_part, *dlogW_part, *dbmu2_part, *dminit_part, *dimean_part, *sacc_part;
+};
+
+template <int DX, int DY>
+struct BAcc {
+    static constexpr int kSc = 0;           // PoG: direct d c
+    static constexpr int kSmm1 = DX;        // sum dmu * mu1
+    static constexpr int kSmb = 2 * DX;     // sum dmu * bmu2
+    static constexpr int kSmm = 3 * DX;     // sum dmu * mu
+    static constexpr int kSf = 4 * DX;      // d sigma_f
+    static constexpr int kSinit = 5 * DX;   // d sigma_init
+    static constexpr int kSiota = 6 * DX;   // d isig
+    static constexpr int kSg = 7 * DX;      // d sigma_g (DY)
+    static constexpr int kN = 7 * DX + DY;
+};
+
+template <int DX>
+struct BTileSlot {
+    static constexpr int kFloats = (DX <= 3) ? 4 : 8;
+};
+
+__device__ __forceinline__ float quad_bcast_b(float v, int lane, int i) { return __shfl(v, (lane & ~3) | i); }
+
+template <int DX>
+__device__ __forceinline__ void read_slot(const float* p, float (&F)[DX], float& W) {
+    const float4 e = *reinterpret_cast<const float4*>(p);
+    if constexpr (DX <= 3) {
+        F[0] = e.x;
+        if constexpr (DX > 1) F[1] = e.y;
+        if constexpr (DX > 2) F[2] = e.z;
+        W = e.w;
+    } else {
+        F[0] = e.x; F[1] = e.y; F[2] = e.z; F[3] = e.w;
+        W = p[4];
+    }
+}
+
+// One butterfly stage of the reduce-scatter over quads: the NN live entries are halved; the lane
+// keeps the half selected by its `bit` and adds the partner's (lane ^ mask) copy of that half.
+template <int CH, int NA, int NN>
+__device__ __forceinline__ void rs_stage(float (&A)[CH][NA], int bit, int mask) {
+#pragma unroll
+    for (int i = 0; i < NN / 2; ++i) {
+#pragma unroll
+        for (int d = 0; d < NA; ++d) {
+            const float lo = A[i][d], hi = A[i + NN / 2][d];
+            const float send = bit ? lo : hi;
+            const float keep = bit ? hi : lo;
+            A[i][d] = keep + __shfl_xor(send, mask);
+        }
+    }
+}
+
+// lane-id bit of the s-th butterfly stage: the quad-index bits are lane bits 2..5; with HS = 2 the bit
+// that selects the chain half (bit log2(M)) is skipped -- the halves walk different forward particles.
+template <int M, int HS>
+__device__ __host__ constexpr int stage_bit(int s) {
+    int hb = 0;
+    while ((1 << hb) < M) ++hb;
+    int k = -1;
+    for (int bit = 2; bit <= 5; ++bit) {
+        if (HS == 2 && bit == hb) continue;
+        if (++k == s) return bit;
+    }
+    return 5;
+}
+
+// HS as in bsim_fwd.hip: HS = 2 spreads a chain over 2*M lanes (half the forward particles and half the
+// hidden units of every MLP per lane) so that small problems still run two waves per SIMD.
+template <int DX, int DY, int H, int M, int CH, int HS>
+__global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    using AC = BAcc<DX, DY>;
+    constexpr int PS = BTileSlot<DX>::kFloats;
+    constexpr int kMaxStage = 4;
+    constexpr bool kRolled = true;
+    constexpr int NA = DX + 1;  // per-j accumulators: dF (DX) and dW
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NTB = blockDim.x, nwv = NTB >> 6;
+    const int B = a.B, T = a.T, N = a.N;
+    const int NP = (N + 3) & ~3;
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    constexpr int G = M * HS;
+    constexpr int NS = (HS == 2) ? 3 : 4;  // butterfly stages (quads that share a forward-particle range)
+    const int cpb = NTB / G;
+    const int cl = tid / G, hpart = (tid % G) / M, m = tid % M, q = m & 3;
+    const bool h0 = (hpart == 0);
+    const int n_raw = blk * cpb + cl;
+    const bool valid = n_raw < N;
+    const int n = valid ? n_raw : N - 1;
+    const int gbase = lane - m;
+
+    float* wf = smem;
+    float* wg = wf + MQ::kSize;
+    float* wqi = wg + MG::kSize;
+    float* tile = wqi + MQ::kSize;               // [2][NP][PS]
+    float* jacc = tile + 2 * NP * PS;            // [nwv][NA][NP] wave-private d F' / d W accumulators
+    float* red = jacc + nwv * NA * NP;           // [cpb][DX] + 16
+
+    MQ::load(wf, a.f, tid, NTB);
+    MG::load(wg, a.g, tid, NTB);
+    MQ::load(wqi, a.q1inv, tid, NTB);
+    for (int i = tid; i < nwv * NA * NP; i += NTB) jacc[i] = 0.f;
+
+    // ---- constants ----------------------------------------------------------------------------
+    const float kappa = sqrtf(0.5f * kLog2e);  // rho_d * sigma_d
+    float sf[DX], isf[DX], rp[DX], isg[DY];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        sf[d] = a.sig_f[d];
+        isf[d] = 1.f / sf[d];
+        rp[d] = isf[d] * kappa;
+    }
+#pragma unroll
+    for (int e = 0; e < DY; ++e) isg[e] = 1.f / a.sig_g[e];
+    float pc[DX], pic[DX], pi1[DX], pi2[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        pi1[d] = 1.f / a.sig_q1inv[d];
+        pi2[d] = 1.f / a.sig_bq2[d];
+        pic[d] = pi1[d] + pi2[d];
+        pc[d] = 1.f / pic[d];
+    }
+    float s_init[DX], i_isig[DX], im[DX], mi[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        s_init[d] = a.sig_init[d];
+        i_isig[d] = 1.f / a.isig[d];
+        im[d] = a.imean[b * DX + d];
+        mi[d] = a.minit[b * DX + d];
+    }
+    const float ninf = -__builtin_huge_valf();
+    const float aw = valid ? a.dscore[(size_t)b * N + n] : 0.f;  // d loss / d score of this chain
+
+    // ---- forward-tile staging (identical image to the forward kernel) -----------------------------------
+    float st[kMaxStage][DX + 1];
+    auto stage_load = [&](int tt) {
+        const size_t tb = (size_t)tt * B + b;
+        const float l = a.lse[tb];
+#pragma unroll
+        for (int r = 0; r < kMaxStage; ++r) {
+            const int j = tid + r * NTB;
+            if (j < NP) {
+                const int jc = j < N ? j : N - 1;
+#pragma unroll
+                for (int d = 0; d < DX; ++d) st[r][d] = a.Fm[(tb * DX + d) * N + jc] * rp[d];
+                st[r][DX] = j < N ? (a.logW[tb * N + jc] - l) * kLog2e : ninf;
+            }
+        }
+    };
+    auto stage_store = [&](float* buf) {
+#pragma unroll
+        for (int r = 0; r < kMaxStage; ++r) {
+            const int j = tid + r * NTB;
+            if (j < NP) {
+                if constexpr (DX <= 3) {
+                    float4 v;
+                    v.x = st[r][0];
+                    v.y = DX > 1 ? st[r][DX > 1 ? 1 : 0] : 0.f;
+                    v.z = DX > 2 ? st[r][DX > 2 ? 2 : 0] : 0.f;
+                    v.w = st[r][DX];
+                    *reinterpret_cast<float4*>(buf + j * PS) = v;
+                } else {
+                    *reinterpret_cast<float4*>(buf + j * PS) = make_float4(st[r][0], st[r][1], st[r][2], st[r][3]);
+                    *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(st[r][4], 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    };
+    // step t reads forward tile t-1; first tile needed is tile(0) at t = 1
+    if (T >= 2) {
+        stage_load(0);
+        stage_store(tile);
+    }
+    __syncthreads();
+
+    float acc[AC::kN];
+#pragma unroll
+    for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
+    float dX[DX];  // d loss / d bwX_t of this chain (all M lanes hold the same value)
+#pragma unroll
+    for (int d = 0; d < DX; ++d) dX[d] = 0.f;
+
+    const int nq = NP >> 2;               // forward-tile entries per quad lane
+    const int nqh = (nq + HS - 1) / HS;   // ... per chain half
+    const int e0 = hpart * nqh, e1 = min(nq, (hpart + 1) * nqh);
+
+    for (int t = 0; t < T; ++t) {
+        const size_t tb = (size_t)t * B + b;
+        const bool last = (t == T - 1), first = (t == 0);
+        const float* cur = tile + ((t + 1) & 1) * NP * PS;  // tile(t-1), valid for t >= 1
+        float* nxt = tile + (t & 1) * NP * PS;              // tile(t) for step t+1
+        if (t + 1 < T && t >= 1) stage_load(t);             // (tile(0) was staged in the prologue)
+
+        // ---- recompute the proposal ---------------------------------------------------------------------
+        float xp[DX], eps[DX], bm[DX], mu1[DX], mu[DX], x[DX], y[DY];
+        const int sel = a.sel[tb * N + n];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            eps[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
+            bm[d] = a.bmu2[tb * DX + d];
+            if (!last) {
+                xp[d] = a.bwX[((tb + B) * DX + d) * N + n];
+                mu1[d] = a.mu1_all[(tb * DX + d) * N + n];
+                mu[d] = pc[d] * fmaf(pi1[d], mu1[d], pi2[d] * bm[d]);
+                x[d] = fmaf(pc[d], eps[d], mu[d]);
+            } else {
+                xp[d] = 0.f;
+                mu1[d] = 0.f;
+                mu[d] = mi[d];
+                x[d] = fmaf(s_init[d], eps[d], mu[d]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+        const float pi_m = valid ? expf(a.om_all[(tb * N + n) * M + m]) : 0.f;
+        const float issel = (m == sel) ? 1.f : 0.f;
+        const float dphi = aw * pi_m;                 // = d g_m = d iota_m
+        const float dlam = -aw * (issel - pi_m);
+
+        float dxt[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) dxt[d] = h0 ? issel * dX[d] : 0.f;  // dxt: this lane's PARTIAL of d x~_m
+
+        // ---- filter term: second pass over the forward tile -------------------------------------------------
+#ifdef PSVO_EXP_NOPAIR
+        if (false) {
+#else
+        if (!first) {
+#endif
+            const float lam2 = a.lam2_all[(tb * N + n) * M + m];
+            float xq[4][DX], lq[4], dl[4], U[4][DX], V[4][DX];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lq[i] = quad_bcast_b(lam2, lane, i);
+                dl[i] = quad_bcast_b(dlam, lane, i);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    xq[i][d] = quad_bcast_b(x[d] * rp[d], lane, i);
+                    U[i][d] = 0.f;
+                    V[i][d] = 0.f;
+                }
+            }
+            float* ja = jacc + wave * NA * NP;
+            // The walk over j is done in chunks of CH entries kept in registers; after each chunk the
+            // per-j partial sums (over this quad's four m) are reduce-scattered across the 16 quads
+            // of the wave (lane bits 2..5) with a 4-stage butterfly, so every lane ends up owning
+            // CH/16 fully reduced (j, d) sums which it stores -- no atomics, fixed summation order.
+            for (int c0 = e0; c0 < e1; c0 += CH) {
+                float A[CH][NA];
+#pragma unroll
+                for (int i2 = 0; i2 < CH; ++i2) {
+                    const int e = c0 + i2;
+#pragma unroll
+                    for (int d = 0; d < NA; ++d) A[i2][d] = 0.f;
+                    if (e < e1) {
+                        const int j = e * 4 + q;
+                        float F[DX], W;
+                        read_slot<DX>(cur + j * PS, F, W);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float u[DX], l = W;
+#pragma unroll
+                            for (int d = 0; d < DX; ++d) {
+                                u[d] = xq[i][d] - F[d];
+                                l = fmaf(-u[d], u[d], l);
+                            }
+                            const float p = exp2_fast(l - lq[i]);
+                            const float c = dl[i] * p;
+                            A[i2][DX] += c;
+#pragma unroll
+                            for (int d = 0; d < DX; ++d) {
+                                const float pu = p * u[d];
+                                U[i][d] += pu;
+                                V[i][d] = fmaf(pu, u[d], V[i][d]);
+                                A[i2][d] = fmaf(c, u[d], A[i2][d]);
+                            }
+                        }
+                    }
+                }
+                constexpr int b0 = stage_bit<M, HS>(0), b1 = stage_bit<M, HS>(1), b2 = stage_bit<M, HS>(2);
+                rs_stage<CH, NA, CH>(A, (lane >> b0) & 1, 1 << b0);
+                rs_stage<CH, NA, CH / 2>(A, (lane >> b1) & 1, 1 << b1);
+                rs_stage<CH, NA, CH / 4>(A, (lane >> b2) & 1, 1 << b2);
+                int ebase = ((lane >> b0) & 1) * (CH / 2) + ((lane >> b1) & 1) * (CH / 4) + ((lane >> b2) & 1) * (CH / 8);
+                if constexpr (NS == 4) {
+                    constexpr int b3 = stage_bit<M, HS>(3);
+                    rs_stage<CH, NA, CH / 8>(A, (lane >> b3) & 1, 1 << b3);
+                    ebase += ((lane >> b3) & 1) * (CH / 16);
+                }
+                constexpr int R = CH >> NS;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = c0 + ebase + r;
+                    if (e < e1) {
+#pragma unroll
+                        for (int d = 0; d < NA; ++d) ja[d * NP + e * 4 + q] = A[r][d];
+                    }
+                }
+            }
+            // merge the quad's four j-slices; lane q keeps sub-particle i == q
+            float Uo[DX], Vo[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                Uo[d] = 0.f;
+                Vo[d] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    float u = U[i][d], v = V[i][d];
+                    u += __shfl_xor(u, 1);
+                    u += __shfl_xor(u, 2);
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    if (i == q) {
+                        Uo[d] = u;
+                        Vo[d] = v;
+                    }
+                }
+            }
+            // (x~-F)/sigma^2 = u / (sigma kappa);  z^2 = u^2 / kappa^2
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                // U, V cover this half's forward particles only: partial sums; the "-1" is counted once
+                dxt[d] -= dlam * Uo[d] * isf[d] / kappa;
+                acc[AC::kSf + d] += dlam * (Vo[d] / (kappa * kappa) - (h0 ? 1.f : 0.f)) * isf[d];
+            }
+        } else {
+            // t = 0: iota_m = LN(x~; imean, isig)   (reference PSVO.py:169-175)
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                const float z = (x[d] - im[d]) * i_isig[d];
+                const float tz = dphi * z * i_isig[d];
+                if (h0) {
+                    dxt[d] -= tz;
+                    acc[AC::kSiota + d] += dphi * (z * z - 1.f) * i_isig[d];
+                }
+            }
+        }
+
+        // ---- f(x_{t+1} | x~), g(y_t | x~) ------------------------------------------------------------------------
+        float dxp_part[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) dxp_part[d] = 0.f;
+        {
+            float dFo[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) dFo[d] = 0.f;
+            if (!last) {
+                float fmx[DX];
+                if constexpr (HS == 1) {
+                    MQ::template eval<kRolled>(wf, x, fmx);
+                } else {
+                    MQ::template eval_part<HS>(wf, hpart, x, fmx);
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) fmx[d] += __shfl_xor(fmx[d], M);
+                }
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    const float z = (xp[d] - fmx[d]) * isf[d];
+                    dFo[d] = dphi * z * isf[d];
+                    if (h0) {
+                        dxp_part[d] = -dFo[d];
+                        acc[AC::kSf + d] += dphi * (z * z - 1.f) * isf[d];
+                    }
+                }
+                if constexpr (HS == 1) MQ::template bwd_input<kRolled>(wf, x, dFo, dxt);
+                else MQ::template bwd_input_part<HS>(wf, hpart, x, dFo, dxt);
+            }
+            if (valid && h0) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    a.dFt[((tb * DX + d) * N + n) * M + m] = dFo[d];
+                    a.xt[((tb * DX + d) * N + n) * M + m] = x[d];
+                }
+            }
+            float gm[DY], dGo[DY];
+            if constexpr (HS == 1) {
+                MG::template eval<kRolled>(wg, x, gm);
+            } else {
+                MG::template eval_part<HS>(wg, hpart, x, gm);
+#pragma unroll
+                for (int k = 0; k < DY; ++k) gm[k] += __shfl_xor(gm[k], M);
+            }
+#pragma unroll
+            for (int k = 0; k < DY; ++k) {
+                const float z = (y[k] - gm[k]) * isg[k];
+                dGo[k] = dphi * z * isg[k];
+                if (h0) acc[AC::kSg + k] += dphi * (z * z - 1.f) * isg[k];
+                if (valid && h0) a.dGt[((tb * DY + k) * N + n) * M + m] = dGo[k];
+            }
+            if constexpr (HS == 1) MG::template bwd_input<kRolled>(wg, x, dGo, dxt);
+            else MG::template bwd_input_part<HS>(wg, hpart, x, dGo, dxt);
+        }
+
+        // ---- reduce over the chain's M sub-particles ------------------------------------------------------------
+        float dmu[DX], sce[DX], dxp[DX], dim[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            float v0 = dxt[d], v1 = dxt[d] * eps[d], v2 = dxp_part[d];
+            float v3 = (first && h0) ? dphi * (x[d] - im[d]) * i_isig[d] * i_isig[d] : 0.f;
+#pragma unroll
+            for (int o = 1; o < G; o <<= 1) {  // over the M sub-particles and the HS halves
+                v0 += __shfl_xor(v0, o);
+                v1 += __shfl_xor(v1, o);
+                v2 += __shfl_xor(v2, o);
+                v3 += __shfl_xor(v3, o);
+            }
+            dmu[d] = v0;
+            sce[d] = v1;
+            dxp[d] = v2;
+            dim[d] = v3;
+        }
+        const bool lead = (m == 0) && h0 && valid;
+        float outv[DX];  // per-chain value that is summed over the workgroup: d bmu2 / d minit
+        if (!last) {
+            float dmu1[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                dmu1[d] = dmu[d] * pc[d] * pi1[d];
+                outv[d] = dmu[d] * pc[d] * pi2[d];
+                if (lead) {
+                    a.dmu1[(tb * DX + d) * N + n] = dmu1[d];
+                    acc[AC::kSc + d] += sce[d] + aw * pic[d];   // -sum_m dq_m / c = a / c
+                    acc[AC::kSmm1 + d] += dmu[d] * mu1[d];
+                    acc[AC::kSmb + d] += dmu[d] * bm[d];
+                    acc[AC::kSmm + d] += dmu[d] * mu[d];
+                }
+            }
+            if constexpr (HS == 1) {
+                MQ::template bwd_input<kRolled>(wqi, xp, dmu1, dxp);
+            } else {
+                float dq[DX];
+#pragma unroll
+                for (int d = 0; d < DX; ++d) dq[d] = 0.f;
+                MQ::template bwd_input_part<HS>(wqi, hpart, xp, dmu1, dq);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) dxp[d] += dq[d] + __shfl_xor(dq[d], M);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                outv[d] = dmu[d];
+                if (lead) {
+                    a.dmu1[(tb * DX + d) * N + n] = 0.f;
+                    acc[AC::kSinit + d] += sce[d] + aw / s_init[d];
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DX; ++d) dX[d] = dxp[d];
+
+        // ---- workgroup reductions: d bmu2[t] / d minit, d imean; flush d Fm / d logW partials ---------------------------
+        if (m == 0 && h0) {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                red[cl * DX + d] = valid ? outv[d] : 0.f;
+                red[(cpb + cl) * DX + d] = valid ? dim[d] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (tid < DX) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int c = 0; c < cpb; ++c) {
+                s0 += red[c * DX + tid];
+                s1 += red[(cpb + c) * DX + tid];
+            }
+            if (!last) a.dbmu2_part[(tb * nblk + blk) * DX + tid] = s0;
+            else {
+                a.dbmu2_part[(tb * nblk + blk) * DX + tid] = 0.f;
+                a.dminit_part[((size_t)b * nblk + blk) * DX + tid] = s0;
+            }
+            if (first) a.dimean_part[((size_t)b * nblk + blk) * DX + tid] = s1;
+        }
+        if (!first) {
+            // forward step t-1 receives d F (un-prescale: d F = d F' * rho, and the 1/(sigma kappa) factor)
+            const size_t tbm = tb - B;
+            for (int i = tid; i < NA * N; i += NTB) {
+                const int d = i / N, j = i - d * N;
+                float s = 0.f;
+                for (int w = 0; w < nwv; ++w) s += jacc[(w * NA + d) * NP + j];
+                if (d < DX) a.dFm_part[((tbm * nblk + blk) * DX + d) * N + j] = s * isf[d] / kappa;
+                else a.dlogW_part[(tbm * nblk + blk) * N + j] = s;
+            }
+        }
+        if (last) {
+            for (int i = tid; i < NA * N; i += NTB) {
+                const int d = i / N, j = i - d * N;
+                if (d < DX) a.dFm_part[((tb * nblk + blk) * DX + d) * N + j] = 0.f;
+                else a.dlogW_part[(tb * nblk + blk) * N + j] = 0.f;
+            }
+        }
+        if (t + 1 < T && t >= 1) stage_store(nxt);
+        __syncthreads();
+    }
+
+    // ---- scalar accumulators: reduce over the workgroup ---------------------------------------------------------------
+    for (int i = 0; i < AC::kN; ++i) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < AC::kN; ++k) v = (k == i) ? acc[k] : v;
+        v = wave_sum(v);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < nwv; ++w) s += red[w];
+            a.sacc_part[((size_t)b * nblk + blk) * AC::kN + i] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// fold (B * nblk, NACC) partial sums into scale gradients (see filter_bwd_finalize for the PoG algebra)
+template <int DX, int DY>
+__global__ void bsim_bwd_finalize(const float* __restrict__ sacc, int rows, const float* sig_q1inv,
+                                  const float* sig_bq2, float* dsig_f, float* dsig_g, float* dsig_q1inv,
+                                  float* dsig_bq2, float* dsig_init, float* disig) {
+    using AC = BAcc<DX, DY>;
+    __shared__ float tot[AC::kN];
+    const int d = threadIdx.x;
+    for (int k = 0; k < AC::kN; ++k) {  // one wave: lanes stride over the (sequence, workgroup) rows
+        float v = 0.f;
+        for (int r = d; r < rows; r += 64) v += sacc[(size_t)r * AC::kN + k];
+        v = wave_sum(v);
+        if (d == 0) tot[k] = v;
+    }
+    __syncthreads();
+    auto total = [&](int k) { return tot[k]; };
+    if (d < DX) {
+        const float i1 = 1.f / sig_q1inv[d], i2 = 1.f / sig_bq2[d];
+        const float c = 1.f / (i1 + i2);
+        const float dc = total(AC::kSc + d) + total(AC::kSmm + d) / c;
+        const float di1 = c * total(AC::kSmm1 + d) - c * c * dc;
+        const float di2 = c * total(AC::kSmb + d) - c * c * dc;
+        dsig_q1inv[d] = -i1 * i1 * di1;
+        dsig_bq2[d] = -i2 * i2 * di2;
+        dsig_f[d] = total(AC::kSf + d);
+        dsig_init[d] = total(AC::kSinit + d);
+        disig[d] = total(AC::kSiota + d);
+    }
+    if (d < DY) dsig_g[d] = total(AC::kSg + d);
+}
+
+struct BsimBwdOut {
+    float *dsig_f, *dsig_g, *dsig_q1inv, *dsig_bq2, *dsig_init, *disig;
+};
+
+static inline void bsim_geometry(int B, int N, int M, int H, int& HS, int& NTB, int& cpb, int& nblk) {
+    // fewer than two waves per SIMD (1024 SIMDs) with one lane per (chain, m): spread a chain over 2M lanes
+    const long long waves1 = ((long long)B * N * M + 63) / 64;
+    HS = (waves1 < 2048 && 2 * M <= 64 && (H / 2) % 4 == 0) ? 2 : 1;
+    NTB = ((N * M * HS + 63) / 64) * 64;
+    if (NTB > 256) NTB = 256;
+    cpb = NTB / (M * HS);
+    nblk = (N + cpb - 1) / cpb;
+}
+
+template <int DX, int DY, int H, int M>
+static int launch_bsim_bwd(const BsimBwdArgs& a, const BsimBwdOut& o, hipStream_t stream) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    using AC = BAcc<DX, DY>;
+    constexpr int PS = BTileSlot<DX>::kFloats;
+    const int NP = (a.N + 3) & ~3;
+    int HS, NTB, cpb, nblk;
+    bsim_geometry(a.B, a.N, M, H, HS, NTB, cpb, nblk);
+    const int nwv = NTB / 64;
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nwv * (DX + 1) * NP +
+                                        2 * cpb * DX + 16);
+    clear_hip_error();
+    // chunk of forward-tile entries reduced in registers per butterfly: 32 when a lane walks >= 32 entries
+    const int walk = (NP / 4 + HS - 1) / HS;
+    if (HS == 2) {
+        if constexpr (2 * M <= 64 && (H / 2) % 4 == 0) {
+            if (walk >= 32)
+                hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 32, 2>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
+            else
+                hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 16, 2>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
+        }
+    } else if (walk >= 32) {
+        hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 32, 1>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 16, 1>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
+    }
+    hipLaunchKernelGGL((bsim_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc_part, a.B * nblk,
+                       a.sig_q1inv, a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
+    (void)AC::kN;
+    return launch_status();
+}
+
+template <int DX, int DY, int H>
+static int bb_dispatch_m(const BsimBwdArgs& a, const BsimBwdOut& o, int M, hipStream_t s) {
+    switch (M) {
+        case 4: return launch_bsim_bwd<DX, DY, H, 4>(a, o, s);
+        case 8: return launch_bsim_bwd<DX, DY, H, 8>(a, o, s);
+        case 16: return launch_bsim_bwd<DX, DY, H, 16>(a, o, s);
+        case 32: return launch_bsim_bwd<DX, DY, H, 32>(a, o, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+template <int DX, int DY>
+static int bb_dispatch_h(const BsimBwdArgs& a, const BsimBwdOut& o, int H, int M, hipStream_t s) {
+    switch (H) {
+        case 16: return bb_dispatch_m<DX, DY, 16>(a, o, M, s);
+        case 32: return bb_dispatch_m<DX, DY, 32>(a, o, M, s);
+        case 64: return bb_dispatch_m<DX, DY, 64>(a, o, M, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+// external linkage: explicitly instantiated once per DX in bsim_bwd_dx{2,3,4}.hip (compiled in parallel)
+template <int DX>
+int bb_dispatch_dy(const BsimBwdArgs& a, const BsimBwdOut& o, int Dy, int H, int M, hipStream_t s) {
+    switch (Dy) {
+        case 1: return bb_dispatch_h<DX, 1>(a, o, H, M, s);
+        case 2: return bb_dispatch_h<DX, 2>(a, o, H, M, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace psvo
+

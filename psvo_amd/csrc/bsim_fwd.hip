@@ -51,7 +51,11 @@ __device__ __forceinline__ void lse2_merge(float& m, float& s, float m2, float s
     m = nm;
 }
 
-template <int DX, int DY, int H, int M>
+// HS = 1: lane = (chain, m).  HS = 2: lane = (chain, half, m) -- the two halves of a chain split the
+// walk over the forward particles and the hidden units of every MLP evaluation, so a chain step is
+// spread over 2*M lanes.  At C* (65536 (chain, m) pairs = one wave per SIMD, where a lone wave issues
+// one VALU op per 4 cycles) this doubles the resident waves per SIMD.
+template <int DX, int DY, int H, int M, int HS>
 __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
@@ -65,8 +69,10 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
     const int B = a.B, T = a.T, N = a.N;
     const int NP = (N + 3) & ~3;
     const int b = blockIdx.y;
-    const int cpb = NTB / M;
-    const int cl = tid / M, m = tid % M, q = m & 3;
+    constexpr int G = M * HS;  // lanes per chain
+    const int cpb = NTB / G;
+    const int cl = tid / G, hpart = (tid % G) / M, m = tid % M, q = m & 3;
+    const bool lead = (m == 0) && (hpart == 0);
     const int n_raw = blockIdx.x * cpb + cl;
     const bool valid = n_raw < N;
     const int n = valid ? n_raw : N - 1;
@@ -212,8 +218,14 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
             q_lp = diag_lp<DX>(x, mu, is_init, kinit);
         } else {
             float m1[DX], mu[DX];
-            MQ::template eval<kRolled>(wqi, xp, m1);
-            if (a.mu1_all && valid && m == 0) {
+            if constexpr (HS == 1) {
+                MQ::template eval<kRolled>(wqi, xp, m1);
+            } else {
+                MQ::template eval_part<HS>(wqi, hpart, xp, m1);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) m1[d] += __shfl_xor(m1[d], M);
+            }
+            if (a.mu1_all && valid && lead) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) a.mu1_all[(tb * DX + d) * N + n] = m1[d];
             }
@@ -229,11 +241,23 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         float phi = 0.f;
         if (!last) {
             float fmx[DX];
-            MQ::template eval<kRolled>(wf, x, fmx);
+            if constexpr (HS == 1) {
+                MQ::template eval<kRolled>(wf, x, fmx);
+            } else {
+                MQ::template eval_part<HS>(wf, hpart, x, fmx);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) fmx[d] += __shfl_xor(fmx[d], M);
+            }
             phi = diag_lp<DX>(xp, fmx, isf, kf);
         }
         float gm[DY];
-        MG::template eval<kRolled>(wg, x, gm);
+        if constexpr (HS == 1) {
+            MG::template eval<kRolled>(wg, x, gm);
+        } else {
+            MG::template eval_part<HS>(wg, hpart, x, gm);
+#pragma unroll
+            for (int k = 0; k < DY; ++k) gm[k] += __shfl_xor(gm[k], M);
+        }
         const float g_lp = diag_lp<DY>(obs_c, gm, isg, kg);
 
         // ---- filter term: logsumexp_j( log f(x~ | X_{t-1}[j]) + W^_{t-1}[j] ) -----------------------
@@ -251,9 +275,11 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
                 sm[i] = 0.f;
             }
             // lane walks j = q, q+4, ...; chunks of 4 such j per online-lse update
-            const int nq = NP >> 2;  // entries per quad lane
-            int jj = 0;
-            for (; jj + 4 <= nq; jj += 4) {
+            const int nq = NP >> 2;               // forward-tile entries per quad lane
+            const int nqh = (nq + HS - 1) / HS;   // ... per half
+            const int e1 = min(nq, (hpart + 1) * nqh);
+            int jj = hpart * nqh;
+            for (; jj + 4 <= e1; jj += 4) {
                 float v[4][4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -296,7 +322,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
                     mx[i] = nm;
                 }
             }
-            for (; jj < nq; ++jj) {  // remainder entries
+            for (; jj < e1; ++jj) {  // remainder entries
                 const float* p = cur + (jj * 4 + q) * PS;
                 float F[DX], W;
                 if constexpr (DX <= 3) {
@@ -337,9 +363,13 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
                     ls = ss;
                 }
             }
+            if constexpr (HS == 2) {  // the other half of the chain walked the other forward particles
+                const float m2 = __shfl_xor(lm, M), s2 = __shfl_xor(ls, M);
+                lse2_merge(lm, ls, m2, s2);
+            }
             const float lam2 = lm + log2_fast(ls);
             lam = fmaf(kLn2, lam2, kf);
-            if (a.lam2_all && valid) a.lam2_all[(tb * N + n) * M + m] = lam2;
+            if (a.lam2_all && valid && hpart == 0) a.lam2_all[(tb * N + n) * M + m] = lam2;
         } else {
             lam = diag_lp<DX>(x, im, i_isig, kiota);  // t = 0: q0 / f density at mu_0 (PSVO.py:169-175)
         }
@@ -358,7 +388,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         }
         const float total = __shfl(cdfv, gbase + M - 1);
         const float omega = om_raw - (omx + logf(total));
-        if (a.om_all && valid) a.om_all[(tb * N + n) * M + m] = omega;
+        if (a.om_all && valid && hpart == 0) a.om_all[(tb * N + n) * M + m] = omega;
         int sel;
         if (a.sel_in) {
             sel = sel_c;
@@ -378,7 +408,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         const float lam_s = __shfl(lam, src);
         const float Om = om_s + q_s + logM;
 
-        if (valid && m == 0) {
+        if (valid && lead) {
 #pragma unroll
             for (int d = 0; d < DX; ++d) a.bwX[(tb * DX + d) * N + n] = xs[d];
             a.glp[tb * N + n] = g_s;
@@ -403,7 +433,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         if (t >= 2) stage_store(nxt);
         __syncthreads();
     }
-    if (valid && m == 0) a.score[(size_t)b * N + n] = score;
+    if (valid && lead) a.score[(size_t)b * N + n] = score;
 }
 
 template <int DX, int DY, int H, int M>
@@ -412,13 +442,21 @@ static int launch_bsim(const BsimArgs& a, hipStream_t stream) {
     using MG = MlpLds<DX, H, DY>;
     constexpr int PS = TileSlot<DX>::kFloats;
     const int NP = (a.N + 3) & ~3;
-    int NTB = ((a.N * M + 63) / 64) * 64;
+    // fewer than two waves per SIMD (1024 SIMDs) with one lane per (chain, m): spread each chain over 2M lanes
+    const long long waves1 = ((long long)a.B * a.N * M + 63) / 64;
+    const int HS = (waves1 < 2048 && 2 * M <= 64 && (H / 2) % 4 == 0) ? 2 : 1;
+    int NTB = ((a.N * M * HS + 63) / 64) * 64;
     if (NTB > 256) NTB = 256;
-    const int cpb = NTB / M;
+    const int cpb = NTB / (M * HS);
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS);
     dim3 grid((a.N + cpb - 1) / cpb, a.B);
     clear_hip_error();
-    hipLaunchKernelGGL((bsim_fwd_kernel<DX, DY, H, M>), grid, dim3(NTB), lds, stream, a);
+    if (HS == 2) {
+        if constexpr (2 * M <= 64 && (H / 2) % 4 == 0)
+            hipLaunchKernelGGL((bsim_fwd_kernel<DX, DY, H, M, 2>), grid, dim3(NTB), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((bsim_fwd_kernel<DX, DY, H, M, 1>), grid, dim3(NTB), lds, stream, a);
+    }
     return launch_status();
 }
 

@@ -95,6 +95,61 @@ struct MlpLds {
         }
     }
 
+    // Partial evaluation over the hidden units [part*H/S, (part+1)*H/S): S lanes share one MLP
+    // evaluation and the caller sums `out` over them (xor-shuffles).  b2 is contributed by part 0.
+    template <int S>
+    __device__ __forceinline__ static void eval_part(const float* __restrict__ w, int part, const float (&x)[DIN],
+                                                     float (&out)[DOUT]) {
+        constexpr int HP = H / S;
+        static_assert(HP % 4 == 0, "hidden slice must be a multiple of 4");
+        const float* wp = w + part * HP;  // shifts k in all three arrays (W1 rows, b1, W2T rows)
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) out[o] = part == 0 ? w[kB2 + o] : 0.f;
+#pragma unroll
+        for (int k = 0; k < HP; k += 4) group4(wp, k, x, out);
+    }
+
+    // dx += partial input gradient over the same hidden slice (caller sums dx over the S lanes)
+    template <int S>
+    __device__ __forceinline__ static void bwd_input_part(const float* __restrict__ w, int part, const float (&x)[DIN],
+                                                          const float (&dout)[DOUT], float (&dx)[DIN]) {
+        constexpr int HP = H / S;
+        const float* wp = w + part * HP;
+#pragma unroll
+        for (int k = 0; k < HP; k += 4) {
+            float4 pre = *reinterpret_cast<const float4*>(wp + kB1 + k);
+            float4 wi[DIN];
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) {
+                wi[i] = *reinterpret_cast<const float4*>(wp + kW1 + i * H + k);
+                pre.x = fmaf(x[i], wi[i].x, pre.x);
+                pre.y = fmaf(x[i], wi[i].y, pre.y);
+                pre.z = fmaf(x[i], wi[i].z, pre.z);
+                pre.w = fmaf(x[i], wi[i].w, pre.w);
+            }
+            float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int o = 0; o < DOUT; ++o) {
+                const float4 wo = *reinterpret_cast<const float4*>(wp + kW2 + o * H + k);
+                dh.x = fmaf(dout[o], wo.x, dh.x);
+                dh.y = fmaf(dout[o], wo.y, dh.y);
+                dh.z = fmaf(dout[o], wo.z, dh.z);
+                dh.w = fmaf(dout[o], wo.w, dh.w);
+            }
+            dh.x = pre.x > 0.f ? dh.x : 0.f;
+            dh.y = pre.y > 0.f ? dh.y : 0.f;
+            dh.z = pre.z > 0.f ? dh.z : 0.f;
+            dh.w = pre.w > 0.f ? dh.w : 0.f;
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) {
+                dx[i] = fmaf(dh.x, wi[i].x, dx[i]);
+                dx[i] = fmaf(dh.y, wi[i].y, dx[i]);
+                dx[i] = fmaf(dh.z, wi[i].z, dx[i]);
+                dx[i] = fmaf(dh.w, wi[i].w, dx[i]);
+            }
+        }
+    }
+
     // dx += (d out / d x)^T dout : recomputes the hidden pre-activations (nothing is stored)
     template <bool ROLLED = false>
     __device__ __forceinline__ static void bwd_input(const float* __restrict__ w, const float (&x)[DIN],
