@@ -153,12 +153,14 @@ def main():
                          % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the PSVO hot path")
+    # one rank per GPU; (rehearsals on a one-GPU box: ranks share the card, PSVO_DIST_BACKEND=gloo)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
     from psvo_amd import dp, ops
     from psvo_amd.optim import FlatParams, TFAdam
-    dp.init(backend="nccl", device=device)
+    dp.init(backend=os.environ.get("PSVO_DIST_BACKEND", "nccl"), device=device)
     dist = torch.distributed if world > 1 else None
 
     wl = WORKLOADS[args.workload]
@@ -176,10 +178,10 @@ def main():
     events = {}
     rec = {"on": False}
 
-    def hook(name, phase):
+    def hook(name, phase, stream):
         if rec["on"]:
             e = torch.cuda.Event(enable_timing=True)
-            e.record()
+            e.record(stream)
             events.setdefault(name, []).append(e)
     ops.set_timing_hook(hook)
 

@@ -6,7 +6,8 @@ import math
 import torch
 
 from .. import ops
-from ..autograd import BsimFunction
+from .. import autograd
+from ..autograd import BsimFunction, Overlap, side_stream
 from .SVO import SVO
 
 
@@ -29,8 +30,12 @@ class PSVO(SVO):
         self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
 
         log = {}
+        # the filter (one workgroup per sequence) is issued on a side stream and overlaps with the encoder,
+        # the backward-proposal means and the noise draws; events order it against the backward simulation
+        self._ov = Overlap(side_stream(obs.device)) if (autograd.OVERLAP and obs.is_cuda) else None
         filt = self.SMC(hidden, obs, noise=noise)                      # pre-resampling X and log_Ws
         bs = self.backward_simulation_w_proposal(filt, obs, noise=noise)
+        self._ov = None
         log_ZSMC = self.compute_log_ZSMC_bsim(bs["score"])
         log["Xs"] = bs["bwX"].permute(1, 0, 3, 2)                      # (B, T, N, Dx)
         log["filter"], log["bsim"] = filt, bs

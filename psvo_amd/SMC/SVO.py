@@ -56,6 +56,11 @@ class SVO:
 
     def _desc(self, M=1):
         H = self.model.q1_tran.Dhs[0]
+        d = self._make_desc(M, H)
+        d._ov = getattr(self, "_ov", None)          # stream-overlap context of this evaluation (PSVO only)
+        return d
+
+    def _make_desc(self, M, H):
         return ops.make_desc(self.batch_size, self.time, self.n_particles, M, self.model.Dx, self.model.Dy, H,
                              resample=self.resample_particles, two_q=self.model.use_2_q,
                              bootstrap=self.model.use_bootstrap)

@@ -11,6 +11,34 @@ import torch
 from . import ops
 
 
+# ---------------------------------------------------------------------------------------------
+# Stream overlap.  The filter kernels run one workgroup per sequence (32 of 256 CUs at C*), so they
+# are issued on a side stream and overlap with work that does not depend on them:
+#   forward : filter  ||  bsim noise draws, observation encoder, hoisted backward-proposal means
+#   backward: filter reverse pass + its weight gradients  ||  weight gradients of the bsim rows,
+#             hoisted-MLP backward, encoder BPTT
+# Synchronisation is by events only (never a device sync).
+# ---------------------------------------------------------------------------------------------
+_SIDE = {}
+OVERLAP = True
+
+
+class Overlap(object):
+    """events shared by the FilterFunction and BsimFunction nodes of ONE objective evaluation"""
+
+    def __init__(self, side):
+        self.side = side
+        self.filter_done = None
+        self.bsim_grads_ready = None
+
+
+def side_stream(device=None):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
 def _cf(t):
     return None if t is None else t.detach().float().contiguous()
 
@@ -37,8 +65,17 @@ class FilterFunction(torch.autograd.Function):
         sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0 = t[12:21]
         if desc.bootstrap:
             f = None
-        filt = ops.filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
-                                  obs_TB, eps, u, idx_in)
+        ov = getattr(desc, "_ov", None)             # shared with the BsimFunction of the same evaluation
+        if ov is not None:                          # PSVO: the consumer (BsimFunction) waits on ov.filter_done
+            ov.side.wait_stream(torch.cuda.current_stream())
+            with ops.launch_on(ov.side):
+                filt = ops.filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
+                                          obs_TB, eps, u, idx_in)
+            ov.filter_done = torch.cuda.Event()
+            ov.filter_done.record(ov.side)
+        else:
+            filt = ops.filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
+                                      obs_TB, eps, u, idx_in)
         ctx.desc, ctx.filt = desc, filt
         ctx.saved = (q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs_TB, eps)
         ctx.mark_non_differentiable(filt["X"], filt["Xanc"], filt["idx"])
@@ -48,8 +85,21 @@ class FilterFunction(torch.autograd.Function):
     def backward(ctx, dlse, dFm, dlogW, *_):
         desc = ctx.desc
         q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs_TB, eps = ctx.saved
-        r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
-                                obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW))
+        ov = getattr(desc, "_ov", None)
+        side = None if ov is None else ov.side
+        ready = None if ov is None else ov.bsim_grads_ready
+        if side is not None and ready is not None:
+            # upstream gradients were produced by BsimFunction.backward (event `ready`); everything issued
+            # on the main stream since then (bsim weight gradients, hoisted backward, encoder BPTT) overlaps
+            main = torch.cuda.current_stream()
+            side.wait_event(ready)
+            with ops.launch_on(side):
+                r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
+                                        obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW))
+            main.wait_stream(side)
+        else:
+            r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
+                                    obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW))
         Dx, Dy, H = desc.Dx, desc.Dy, desc.H
         gq1 = ops.split_mlp_grad(r["gq1"], Dx, H, Dx)
         gf = (None,) * 4 if desc.bootstrap else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
@@ -75,6 +125,9 @@ class BsimFunction(torch.autograd.Function):
         f, g, q = tuple(t[0:4]), tuple(t[4:8]), tuple(t[8:12])
         sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig = t[12:21]
         filt = {"X": None, "Fm": _cf(Fm), "logW": _cf(logW), "lse": _cf(lse)}
+        ov = getattr(desc, "_ov", None)
+        if ov is not None and ov.filter_done is not None:     # the filter ran on the side stream
+            torch.cuda.current_stream().wait_event(ov.filter_done)
         need = any(ctx.needs_input_grad)
         bs = ops.bsim_forward(desc, {**filt, "X": filt["Fm"]}, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit,
                               sig_init, imean, isig, obs_TB, eps_b, u_b, sel_in, save=need)
@@ -95,6 +148,10 @@ class BsimFunction(torch.autograd.Function):
         gq = ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
         dFm = r["dFm_part"].sum(2)          # fold the per-workgroup partials
         dlogW = r["dlogW_part"].sum(2)
+        ov = getattr(desc, "_ov", None)
+        if ov is not None:
+            ov.bsim_grads_ready = torch.cuda.Event()
+            ov.bsim_grads_ready.record()
         return (None, None, None, None, None, dFm, dlogW, None) + tuple(gf) + tuple(gg) + tuple(gq) + (
             r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_part"].sum(2),
             r["dminit_part"].sum(1), r["dsig_init"], r["dimean_part"].sum(1), r["disig"])

@@ -11,8 +11,35 @@ import torch
 from . import _lib
 
 
+# Optional side stream for the native launches of one wrapper call.  Only the *launch* moves: output
+# buffers are still allocated from the current stream's pool, and every tensor handed to the kernel
+# is record_stream()'ed so the caching allocator does not recycle it before the side stream is done.
+_LAUNCH_STREAM = None
+
+
+class launch_on(object):
+    """with ops.launch_on(stream): native kernels of the enclosed wrapper calls go to `stream`."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        global _LAUNCH_STREAM
+        self.prev, _LAUNCH_STREAM = _LAUNCH_STREAM, self.stream
+        return self.stream
+
+    def __exit__(self, *exc):
+        global _LAUNCH_STREAM
+        _LAUNCH_STREAM = self.prev
+        return False
+
+
 def _ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    if _LAUNCH_STREAM is not None:
+        t.record_stream(_LAUNCH_STREAM)
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _chk(t, shape, name, dtype=torch.float32):
@@ -36,6 +63,9 @@ def _mlp_struct(p, Din, H, Dout, name):
     _chk(W2, (H, Dout), name + ".W2")
     _chk(b2, (Dout,), name + ".b2")
     s = _lib.psvo_mlp()
+    if _LAUNCH_STREAM is not None:
+        for t in (W1, b1, W2, b2):
+            t.record_stream(_LAUNCH_STREAM)
     s.W1, s.b1, s.W2, s.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
     return s
 
@@ -47,8 +77,12 @@ def make_desc(B, T, N, M, Dx, Dy, H, resample=True, two_q=True, bootstrap=True):
     return d
 
 
+def _cur_stream():
+    return _LAUNCH_STREAM if _LAUNCH_STREAM is not None else torch.cuda.current_stream()
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_cur_stream().cuda_stream)
 
 
 # Optional instrumentation: bench.py installs a hook that records HIP events (on the stream the
@@ -63,7 +97,7 @@ def set_timing_hook(hook):
 
 def _mark(name, phase):
     if _HOOK is not None:
-        _HOOK(name, phase)
+        _HOOK(name, phase, _cur_stream())
 
 
 def filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
