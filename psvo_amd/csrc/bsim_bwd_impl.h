@@ -224,6 +224,30 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 #pragma unroll
     for (int d = 0; d < DX; ++d) dX[d] = 0.f;
 
+    // per-step inputs, requested one step ahead of their use
+    struct StepIn {
+        float eps[DX], bm[DX], xp[DX], mu1[DX], y[DY], om, lam2;
+        int sel;
+    };
+    auto load_step = [&](int t, StepIn& s) {
+        const size_t tb = (size_t)t * B + b;
+        const bool lst = (t == T - 1);
+        s.sel = a.sel[tb * N + n];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            s.eps[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
+            s.bm[d] = a.bmu2[tb * DX + d];
+            s.xp[d] = lst ? 0.f : a.bwX[((tb + B) * DX + d) * N + n];
+            s.mu1[d] = lst ? 0.f : a.mu1_all[(tb * DX + d) * N + n];
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) s.y[k] = a.obs[tb * DY + k];
+        s.om = a.om_all[(tb * N + n) * M + m];
+        s.lam2 = t >= 1 ? a.lam2_all[(tb * N + n) * M + m] : 0.f;
+    };
+    StepIn cur_in, nxt_in;
+    load_step(0, cur_in);
+
     const int nq = NP >> 2;               // forward-tile entries per quad lane
     const int nqh = (nq + HS - 1) / HS;   // ... per chain half
     const int e0 = hpart * nqh, e1 = min(nq, (hpart + 1) * nqh);
@@ -236,27 +260,26 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         if (t + 1 < T && t >= 1) stage_load(t);             // (tile(0) was staged in the prologue)
 
         // ---- recompute the proposal ---------------------------------------------------------------------
+        if (t + 1 < T) load_step(t + 1, nxt_in);
         float xp[DX], eps[DX], bm[DX], mu1[DX], mu[DX], x[DX], y[DY];
-        const int sel = a.sel[tb * N + n];
+        const int sel = cur_in.sel;
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            eps[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
-            bm[d] = a.bmu2[tb * DX + d];
+            eps[d] = cur_in.eps[d];
+            bm[d] = cur_in.bm[d];
+            xp[d] = cur_in.xp[d];
+            mu1[d] = cur_in.mu1[d];
             if (!last) {
-                xp[d] = a.bwX[((tb + B) * DX + d) * N + n];
-                mu1[d] = a.mu1_all[(tb * DX + d) * N + n];
                 mu[d] = pc[d] * fmaf(pi1[d], mu1[d], pi2[d] * bm[d]);
                 x[d] = fmaf(pc[d], eps[d], mu[d]);
             } else {
-                xp[d] = 0.f;
-                mu1[d] = 0.f;
                 mu[d] = mi[d];
                 x[d] = fmaf(s_init[d], eps[d], mu[d]);
             }
         }
 #pragma unroll
-        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
-        const float pi_m = valid ? expf(a.om_all[(tb * N + n) * M + m]) : 0.f;
+        for (int k = 0; k < DY; ++k) y[k] = cur_in.y[k];
+        const float pi_m = valid ? expf(cur_in.om) : 0.f;
         const float issel = (m == sel) ? 1.f : 0.f;
         const float dphi = aw * pi_m;                 // = d g_m = d iota_m
         const float dlam = -aw * (issel - pi_m);
@@ -271,7 +294,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 #else
         if (!first) {
 #endif
-            const float lam2 = a.lam2_all[(tb * N + n) * M + m];
+            const float lam2 = cur_in.lam2;
             float xq[4][DX], lq[4], dl[4], U[4][DX], V[4][DX];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -536,6 +559,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
             }
         }
         if (t + 1 < T && t >= 1) stage_store(nxt);
+        cur_in = nxt_in;
         __syncthreads();
     }
 

@@ -128,6 +128,51 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
 #pragma unroll
     for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
     float dlnw = 0.f;  // IWAE: gradient w.r.t. the normalised log-weight carried into step t+1
+
+    // Per-step inputs are software-prefetched: everything of step t-1 is requested at the top of step t,
+    // and the ancestor index it gathers through (idx[t-2]) one step earlier still, so the dependent
+    // gather Fm[t-2][idx] never sits on the critical path (two HBM round trips per step otherwise).
+    struct StepIn {
+        float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX], dfm_ext[DX];
+        float logw, lse, dlse, dlw_ext;
+        int anc;
+    };
+    auto load_anc = [&](int t) -> int {  // ancestor of particle n at step t (its parent lives at t-1)
+        return (t >= 1 && a.resample) ? a.idx[((size_t)(t - 1) * B + b) * N + n] : n;
+    };
+    auto load_step = [&](int t, int anc, StepIn& s) {
+        const size_t tb = (size_t)t * B + b;
+        s.anc = anc;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            s.x[d] = a.X[(tb * DX + d) * N + n];
+            s.e[d] = a.eps[(tb * DX + d) * N + n];
+            s.m2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
+            if (t == 0) {
+                s.mean1[d] = a.m0[b * DX + d];
+                s.fmean[d] = a.fm0[b * DX + d];
+            } else {
+                s.fmean[d] = a.Fm[((tb - B) * DX + d) * N + anc];
+                s.mean1[d] = a.bootstrap ? s.fmean[d] : a.P1[((tb - B) * DX + d) * N + anc];
+            }
+            float ext = 0.f;
+            if (a.dFm_ext)
+                for (int p = 0; p < a.nparts; ++p) ext += a.dFm_ext[((tb * a.nparts + p) * DX + d) * N + n];
+            s.dfm_ext[d] = ext;
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) s.y[k] = a.obs[tb * DY + k];
+        s.logw = a.logW[tb * N + n];
+        s.lse = a.lse[tb];
+        s.dlse = a.dlse ? a.dlse[tb] : 0.f;
+        float ext = 0.f;
+        if (a.dlogW_ext)
+            for (int p = 0; p < a.nparts; ++p) ext += a.dlogW_ext[(tb * a.nparts + p) * N + n];
+        s.dlw_ext = ext;
+    };
+    StepIn cur, nxt;
+    int anc_next = load_anc(T - 2);            // ancestor used by step T-2
+    load_step(T - 1, load_anc(T - 1), cur);
     __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
@@ -142,35 +187,31 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
         float* curF = accF + (t & 1) * DX * NT;
         float* nxtF = accF + ((t + 1) & 1) * DX * NT;
 
-        // ---- forward quantities of this step ---------------------------------------------------
+        // ---- forward quantities of this step (prefetched) ----------------------------------------------
+        if (t >= 1) {
+            load_step(t - 1, anc_next, nxt);
+            anc_next = load_anc(t - 2);
+        }
         float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX];
-        int anc = n;
-        if (!first && a.resample) anc = a.idx[(tb - B) * N + n];
+        const int anc = cur.anc;
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            x[d] = a.X[(tb * DX + d) * N + n];
-            e[d] = a.eps[(tb * DX + d) * N + n];
-            m2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
-            if (first) {
-                mean1[d] = a.m0[b * DX + d];
-                fmean[d] = a.fm0[b * DX + d];
-            } else {
-                fmean[d] = a.Fm[((tb - B) * DX + d) * N + anc];
-                mean1[d] = a.bootstrap ? fmean[d] : a.P1[((tb - B) * DX + d) * N + anc];
-            }
+            x[d] = cur.x[d];
+            e[d] = cur.e[d];
+            m2[d] = cur.m2[d];
+            mean1[d] = cur.mean1[d];
+            fmean[d] = cur.fmean[d];
         }
 #pragma unroll
-        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+        for (int k = 0; k < DY; ++k) y[k] = cur.y[k];
         float mu[DX];
 #pragma unroll
         for (int d = 0; d < DX; ++d)
             mu[d] = a.two_q ? K.c[d] * fmaf(K.i1[d], mean1[d], K.i2[d] * m2[d]) : mean1[d];
 
         // ---- gradient w.r.t. logW_t[n] ------------------------------------------------------------
-        const float sm = valid ? expf(a.logW[tb * N + n] - a.lse[tb]) : 0.f;
-        float dlw = a.dlse ? a.dlse[tb] * sm : 0.f;
-        if (a.dlogW_ext)
-            for (int p = 0; p < a.nparts; ++p) dlw += a.dlogW_ext[(tb * a.nparts + p) * N + n];
+        const float sm = valid ? expf(cur.logw - cur.lse) : 0.f;
+        float dlw = cur.dlse * sm + cur.dlw_ext;
         if (!a.resample) {
             const float tot = block_sum(dlnw, red, wave, lane, nw);
             dlw += dlnw - sm * tot;
@@ -211,9 +252,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
         for (int d = 0; d < DX; ++d) {
             dPn[d] = curP[d * NT + tid];
             curP[d * NT + tid] = 0.f;
-            float ext = 0.f;
-            if (a.dFm_ext)
-                for (int p = 0; p < a.nparts; ++p) ext += a.dFm_ext[((tb * a.nparts + p) * DX + d) * N + n];
+            const float ext = cur.dfm_ext[d];
             if (a.bootstrap) {
                 dPn[d] += ext;
                 dFn[d] = 0.f;
@@ -279,6 +318,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
                 }
             }
         }
+        cur = nxt;
 #pragma unroll
         for (int i = 0; i < AC::kSet; ++i) {  // set 0: t = 0, set 1: t >= 1 (static register indices)
             acc[i] += first ? inc[i] : 0.f;
