@@ -249,6 +249,18 @@ int psvo_bilstm_backward(int B, int T, int Din, int Dh, const float* x,
 int psvo_adam_step(float* params, const float* grads, float* m, float* v, long long n, float lr,
                    float beta1, float beta2, float eps, long long step, float grad_scale, void* stream);
 
+/* out[p] (+)= sum_{r < nrows} part[r * stride + p], p < n: folds per-sequence / per-workgroup partial
+ * gradients straight into the flat gradient buffer (deterministic, no atomics). */
+int psvo_reduce_rows(const float* part, int nrows, long long stride, int n, float* out, int accumulate,
+                     void* stream);
+
+/* Scale vectors of all distributions at once: sigma = max(softplus(raw), min), NaN -> 0 first
+ * (tf_mvn.get_sigma, reference src/distribution/mvn.py:80-90) and its gradient
+ * graw (+)= dsig * sigmoid(raw) * [softplus(raw) >= min]. */
+int psvo_sigma_forward(const float* raw, const float* mins, float* sig, int n, void* stream);
+int psvo_sigma_backward(const float* raw, const float* mins, const float* dsig, float* graw, int n,
+                        int accumulate, void* stream);
+
 /* Per-sequence ELBO reductions (no batch mean: the caller averages, so a batch shard can be
  * all-reduced).  filter: out[b] = sum_t lse[t,b] (SVO.compute_log_ZSMC, SVO.py:302-311);
  * bsim: out[b] = logsumexp_n score[b,n] - log N (PSVO.compute_log_ZSMC, PSVO.py:52-67). */

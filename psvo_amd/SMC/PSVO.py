@@ -33,6 +33,7 @@ class PSVO(SVO):
         # the filter (one workgroup per sequence) is issued on a side stream and overlaps with the encoder,
         # the backward-proposal means and the noise draws; events order it against the backward simulation
         self._ov = Overlap(side_stream(obs.device)) if (autograd.OVERLAP and obs.is_cuda) else None
+        self._sigmas = self.model.sigmas()          # every scale vector of this evaluation, one fused launch
         filt = self.SMC(hidden, obs, noise=noise)                      # pre-resampling X and log_Ws
         bs = self.backward_simulation_w_proposal(filt, obs, noise=noise)
         self._ov = None
@@ -59,9 +60,10 @@ class PSVO(SVO):
         minit = self.BSim_q_init.mean(preprocessed_obs[:, -1])                   # (B, Dx)
         mu_0 = self.preprocessed_X0                                              # cached by SMC()
         if not (model.use_bootstrap and model.use_2_q):
-            imean, isig = self.f.mean(mu_0), self.f.get_sigma()                  # PSVO.py:171
+            imean, isig = self.f.mean(mu_0), self._sigma(self.f)                 # PSVO.py:171
         else:
-            imean, isig = self.q0.mean(mu_0), self.q0.get_sigma()                # PSVO.py:173
+            # PSVO.py:173: q0.log_prob(mu_0, .) -- the very MLP_q0(mu_0) / sigma_q0 the filter used at t = 0
+            imean, isig = self._m0, self._sig0
 
         eps_b = noise.get("eps_b")
         if eps_b is None:
@@ -72,11 +74,14 @@ class PSVO(SVO):
         obs_TB = obs.transpose(0, 1).contiguous().float()
 
         # one opaque autograd node: psvo_bsim_forward / psvo_bsim_backward
+        desc = self._desc(M)
+        gb = (self._gbuf(model.f_tran), self._gbuf(model.g_tran), self._gbuf(model.q1_inv_tran))
+        desc._gbufs = gb if all(v is not None for v in gb) else None
         score, bwX, flp, glp, Omega, sel = BsimFunction.apply(
-            self._desc(M), obs_TB, eps_b, u_b, sel_in, filt["Fm"], filt["logW"], filt["lse"],
+            desc, obs_TB, eps_b, u_b, sel_in, filt["Fm"], filt["logW"], filt["lse"],
             *model.f_tran.hip_params(), *model.g_tran.hip_params(), *model.q1_inv_tran.hip_params(),
-            self.f.get_sigma(), self.g.get_sigma(), self.q1_inv.get_sigma(), self.BSim_q2.get_sigma(),
-            bmu2, minit, self.BSim_q_init.get_sigma(), imean, isig)
+            self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
+            bmu2, minit, self._sigma(self.BSim_q_init), imean, isig)
         return {"score": score, "bwX": bwX, "flp": flp, "glp": glp, "Omega": Omega, "sel": sel}
 
     def BS_preprocess_obs(self, obs):

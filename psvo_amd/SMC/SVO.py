@@ -47,6 +47,7 @@ class SVO:
         self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
 
         log = {}
+        self._sigmas = self.model.sigmas()          # every scale vector of this evaluation, one fused launch
         filt = self.SMC(hidden, obs, noise=noise)
         log_ZSMC = self.compute_log_ZSMC(filt["lse"])
         # (T, B, Dx, N) -> (batch_size, time, n_particles, Dx)
@@ -59,6 +60,15 @@ class SVO:
         d = self._make_desc(M, H)
         d._ov = getattr(self, "_ov", None)          # stream-overlap context of this evaluation (PSVO only)
         return d
+
+    def _sigma(self, dist):
+        sig = getattr(self, "_sigmas", None)
+        return dist.get_sigma() if sig is None else sig[id(dist)]
+
+    @staticmethod
+    def _gbuf(tran):
+        """slice of the flat gradient buffer a native backward may accumulate this MLP's gradient into"""
+        return None if tran is None else tran.__dict__.get("_flat_grad")
 
     def _make_desc(self, M, H):
         return ops.make_desc(self.batch_size, self.time, self.n_particles, M, self.model.Dx, self.model.Dy, H,
@@ -89,15 +99,15 @@ class SVO:
 
         # ---- hoisted, particle-independent terms (B*T rows) ------------------------------------
         m0 = self.q0.mean(preprocessed_X0)                                    # (B, Dx)
-        sig0 = self.q0.get_sigma()
+        sig0 = self._sigma(self.q0)
         if both:
             fm0, fsig0 = m0, sig0                                             # f_0 is q0's own density
         else:
-            fm0, fsig0 = self.f.mean(preprocessed_X0), self.f.get_sigma()     # SVO.py:91-92
+            fm0, fsig0 = self.f.mean(preprocessed_X0), self._sigma(self.f)    # SVO.py:91-92
         mu2 = sig_q2 = None
         if model.use_2_q:
             mu2 = self.q2.mean(preprocessed_obs).transpose(0, 1).contiguous()  # (T, B, Dx)
-            sig_q2 = self.q2.get_sigma()
+            sig_q2 = self._sigma(self.q2)
         obs_TB = obs.transpose(0, 1).contiguous().float()
 
         eps = noise.get("eps_f")
@@ -108,12 +118,16 @@ class SVO:
             u = self._rand(T, B, N, device=dev)
 
         f_params = (None,) * 4 if model.use_bootstrap else model.f_tran.hip_params()
-        sig_f = None if model.use_bootstrap else self.f.get_sigma()
+        sig_f = None if model.use_bootstrap else self._sigma(self.f)
+        self._m0, self._sig0 = m0, sig0
+        desc = self._desc()
+        gb = (self._gbuf(model.q1_tran), None if model.use_bootstrap else self._gbuf(model.f_tran), self._gbuf(model.g_tran))
+        desc._gbufs = gb if (gb[0] is not None and gb[2] is not None and (model.use_bootstrap or gb[1] is not None)) else None
         # one opaque autograd node: psvo_filter_forward / psvo_filter_backward
         lse, Fm, logW, X, Xanc, idx = FilterFunction.apply(
-            self._desc(), obs_TB, eps, u, idx_in,
+            desc, obs_TB, eps, u, idx_in,
             *model.q1_tran.hip_params(), *f_params, *model.g_tran.hip_params(),
-            self.q1.get_sigma(), sig_q2, sig_f, self.g.get_sigma(), mu2, m0, sig0, fm0, fsig0)
+            self._sigma(self.q1), sig_q2, sig_f, self._sigma(self.g), mu2, m0, sig0, fm0, fsig0)
         return {"lse": lse, "Fm": Fm, "logW": logW, "X": X, "Xanc": Xanc, "idx": idx, "eps": eps, "u": u}
 
     def compute_log_ZSMC(self, lse):

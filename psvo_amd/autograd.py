@@ -30,6 +30,7 @@ class Overlap(object):
         self.side = side
         self.filter_done = None
         self.bsim_grads_ready = None
+        self.bsim_wgrad_done = None
 
 
 def side_stream(device=None):
@@ -63,6 +64,7 @@ class FilterFunction(torch.autograd.Function):
         t = [_cf(v) for v in t]
         q1, f, g = tuple(t[0:4]), tuple(t[4:8]), tuple(t[8:12])
         sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0 = t[12:21]
+        ctx.gbufs = getattr(desc, "_gbufs", None)     # (q1, f, g) flat-gradient slices or None
         if desc.bootstrap:
             f = None
         ov = getattr(desc, "_ov", None)             # shared with the BsimFunction of the same evaluation
@@ -93,17 +95,25 @@ class FilterFunction(torch.autograd.Function):
             # on the main stream since then (bsim weight gradients, hoisted backward, encoder BPTT) overlaps
             main = torch.cuda.current_stream()
             side.wait_event(ready)
+
+            def before_wgrad():   # the bsim weight gradients accumulate into the same q1 / g slices on the main stream
+                if ov.bsim_wgrad_done is not None:
+                    side.wait_event(ov.bsim_wgrad_done)
             with ops.launch_on(side):
                 r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
-                                        obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW))
+                                        obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
+                                        gbufs=ctx.gbufs, before_wgrad=before_wgrad)
             main.wait_stream(side)
         else:
             r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
-                                    obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW))
+                                    obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
+                                    gbufs=ctx.gbufs)
         Dx, Dy, H = desc.Dx, desc.Dy, desc.H
-        gq1 = ops.split_mlp_grad(r["gq1"], Dx, H, Dx)
-        gf = (None,) * 4 if desc.bootstrap else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
-        gg = ops.split_mlp_grad(r["gg"], Dx, H, Dy)
+        gb = ctx.gbufs or (None, None, None)
+        none4 = (None,) * 4
+        gq1 = none4 if gb[0] is not None else ops.split_mlp_grad(r["gq1"], Dx, H, Dx)
+        gf = none4 if (desc.bootstrap or gb[1] is not None) else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
+        gg = none4 if gb[2] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
         two_q, boot = bool(desc.two_q), bool(desc.bootstrap)
         return (None, None, None, None, None) + tuple(gq1) + tuple(gf) + tuple(gg) + (
             r["dsig_q1"], r["dsig_q2"] if two_q else None, None if boot else r["dsig_f"], r["dsig_g"],
@@ -128,6 +138,7 @@ class BsimFunction(torch.autograd.Function):
         ov = getattr(desc, "_ov", None)
         if ov is not None and ov.filter_done is not None:     # the filter ran on the side stream
             torch.cuda.current_stream().wait_event(ov.filter_done)
+        ctx.gbufs = getattr(desc, "_gbufs", None)             # (f, g, q1_inv) flat-gradient slices or None
         need = any(ctx.needs_input_grad)
         bs = ops.bsim_forward(desc, {**filt, "X": filt["Fm"]}, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit,
                               sig_init, imean, isig, obs_TB, eps_b, u_b, sel_in, save=need)
@@ -140,18 +151,25 @@ class BsimFunction(torch.autograd.Function):
     def backward(ctx, dscore, *_):
         desc = ctx.desc
         f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b = ctx.saved
-        r = ops.bsim_backward(desc, ctx.filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
-                              imean, isig, obs_TB, eps_b, ctx.bs, _cg(dscore))
-        Dx, Dy, H = desc.Dx, desc.Dy, desc.H
-        gf = ops.split_mlp_grad(r["gf"], Dx, H, Dx)
-        gg = ops.split_mlp_grad(r["gg"], Dx, H, Dy)
-        gq = ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
-        dFm = r["dFm_part"].sum(2)          # fold the per-workgroup partials
-        dlogW = r["dlogW_part"].sum(2)
         ov = getattr(desc, "_ov", None)
+
+        def after_kernel():   # d Fm / d logW exist: the filter's reverse pass (side stream) may start
+            if ov is not None:
+                ov.bsim_grads_ready = torch.cuda.Event()
+                ov.bsim_grads_ready.record()
+        r = ops.bsim_backward(desc, ctx.filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
+                              imean, isig, obs_TB, eps_b, ctx.bs, _cg(dscore), gbufs=ctx.gbufs,
+                              after_kernel=after_kernel)
         if ov is not None:
-            ov.bsim_grads_ready = torch.cuda.Event()
-            ov.bsim_grads_ready.record()
+            ov.bsim_wgrad_done = torch.cuda.Event()
+            ov.bsim_wgrad_done.record()
+        Dx, Dy, H = desc.Dx, desc.Dy, desc.H
+        gb = ctx.gbufs or (None, None, None)
+        none4 = (None,) * 4
+        gf = none4 if gb[0] is not None else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
+        gg = none4 if gb[1] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
+        gq = none4 if gb[2] is not None else ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
+        dFm, dlogW = r["dFm"], r["dlogW"]
         return (None, None, None, None, None, dFm, dlogW, None) + tuple(gf) + tuple(gg) + tuple(gq) + (
             r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_part"].sum(2),
             r["dminit_part"].sum(1), r["dsig_init"], r["dimean_part"].sum(1), r["disig"])
@@ -161,7 +179,8 @@ class BiLSTMFunction(torch.autograd.Function):
     """psvo_bilstm_forward / psvo_bilstm_backward: one bidirectional LSTMBlockCell layer."""
 
     @staticmethod
-    def forward(ctx, x, W_fw, b_fw, W_bw, b_bw):
+    def forward(ctx, gbufs, x, W_fw, b_fw, W_bw, b_bw):
+        ctx.gbufs = gbufs                                      # (fw, bw) flat-gradient slices or None
         x, W_fw, b_fw, W_bw, b_bw = (_cf(v) for v in (x, W_fw, b_fw, W_bw, b_bw))
         if any(ctx.needs_input_grad):
             out, cs, gates = ops.bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=True)
@@ -173,5 +192,24 @@ class BiLSTMFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, W_fw, W_bw, out, cs, gates = ctx.saved
-        dx, dWf, dbf, dWb, dbb = ops.bilstm_backward(x, W_fw, W_bw, out, cs, gates, _cg(dout))
-        return dx, dWf, dbf, dWb, dbb
+        dx, dWf, dbf, dWb, dbb = ops.bilstm_backward(x, W_fw, W_bw, out, cs, gates, _cg(dout), gbufs=ctx.gbufs)
+        return None, dx, dWf, dbf, dWb, dbb
+
+
+class SigmaFunction(torch.autograd.Function):
+    """sigma of EVERY distribution in one launch (tf_mvn.get_sigma, reference src/distribution/mvn.py:80-90).
+
+    The raw vectors are contiguous in the flat parameter buffer (`blk` from FlatParams._annotate); the
+    gradient is accumulated straight into the flat gradient buffer, so the parameters only anchor the graph.
+    """
+
+    @staticmethod
+    def forward(ctx, blk, *params):
+        ctx.blk = blk
+        return ops.sigma_forward(blk["raw"], blk["mins"])
+
+    @staticmethod
+    def backward(ctx, dsig):
+        blk = ctx.blk
+        ops.sigma_backward(blk["raw"], blk["mins"], _cg(dsig), blk["grad"], accumulate=True)
+        return (None,) + (None,) * len(blk["dists"])

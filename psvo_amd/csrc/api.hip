@@ -60,3 +60,69 @@ extern "C" int psvo_elbo_bsim(const psvo_desc* desc, const float* score, float* 
                        out, desc->N);
     return psvo::launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// small host-overhead killers: at C* the persistent kernels leave ~1 ms of a training step to
+// ~300 tiny launches, so groups of them are fused here.
+// ---------------------------------------------------------------------------------------------
+namespace psvo {
+
+// out[p] (+)= sum_r part[r * stride + p]   (one wave per output element, fixed order)
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int nrows, long long stride, int n,
+                                   float* __restrict__ out, int accumulate) {
+    const int p = blockIdx.x;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < nrows; r += 64) s += part[(size_t)r * stride + p];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[p] = accumulate ? out[p] + s : s;
+}
+
+// sigma = max(softplus(raw), min) with NaN -> 0 first (reference src/distribution/mvn.py:80-90)
+__global__ void sigma_fwd_kernel(const float* __restrict__ raw, const float* __restrict__ mins, float* __restrict__ sig,
+                                 int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float r = raw[i];
+    float s = r > 20.f ? r : log1pf(expf(r));   // softplus (same threshold as torch / TF for fp32)
+    if (s != s) s = 0.f;
+    sig[i] = fmaxf(s, mins[i]);
+}
+
+// graw (+)= dsig * sigmoid(raw) * [softplus(raw) >= min]
+__global__ void sigma_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ mins,
+                                 const float* __restrict__ dsig, float* __restrict__ graw, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float r = raw[i];
+    const float s = r > 20.f ? r : log1pf(expf(r));
+    const float g = (s == s && s >= mins[i]) ? dsig[i] / (1.f + expf(-r)) : 0.f;
+    graw[i] = accumulate ? graw[i] + g : g;
+}
+
+}  // namespace psvo
+
+extern "C" int psvo_reduce_rows(const float* part, int nrows, long long stride, int n, float* out, int accumulate,
+                                void* stream) {
+    if (!part || !out || nrows <= 0 || n <= 0) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
+    hipLaunchKernelGGL(psvo::reduce_rows_kernel, dim3(n), dim3(64), 0, static_cast<hipStream_t>(stream), part, nrows,
+                       stride, n, out, accumulate);
+    return psvo::launch_status();
+}
+
+extern "C" int psvo_sigma_forward(const float* raw, const float* mins, float* sig, int n, void* stream) {
+    if (!raw || !mins || !sig || n <= 0) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
+    hipLaunchKernelGGL(psvo::sigma_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), raw,
+                       mins, sig, n);
+    return psvo::launch_status();
+}
+
+extern "C" int psvo_sigma_backward(const float* raw, const float* mins, const float* dsig, float* graw, int n,
+                                   int accumulate, void* stream) {
+    if (!raw || !mins || !dsig || !graw || n <= 0) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
+    hipLaunchKernelGGL(psvo::sigma_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), raw,
+                       mins, dsig, graw, n, accumulate);
+    return psvo::launch_status();
+}

@@ -216,6 +216,10 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
                 x[d] = fmaf(s_init[d], eps_c[d], mu[d]);
             }
             q_lp = diag_lp<DX>(x, mu, is_init, kinit);
+            if (a.mu1_all && valid && lead) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.mu1_all[(tb * DX + d) * N + n] = 0.f;
+            }
         } else {
             float m1[DX], mu[DX];
             if constexpr (HS == 1) {

@@ -58,7 +58,9 @@ class StackBiRNN(nn.Module):
             # psvo_bilstm_backward) instead of ~4 T launches of a per-step LSTM
             from .autograd import BiLSTMFunction
             for fw, bw in zip(self.fw, self.bw):
-                h = BiLSTMFunction.apply(h, fw.kernel, fw.bias, bw.kernel, bw.bias)
+                gf, gb = fw.__dict__.get("_flat_grad"), bw.__dict__.get("_flat_grad")
+                gbufs = (gf, gb) if (gf is not None and gb is not None) else None
+                h = BiLSTMFunction.apply(gbufs, h, fw.kernel, fw.bias, bw.kernel, bw.bias)
             return h
         B = h.shape[0]
         for fw, bw in zip(self.fw, self.bw):
@@ -163,6 +165,20 @@ class SSM(nn.Module):
             lim = math.sqrt(6.0 / E0)                        # Dense(Dx, he_uniform)
             self.X0_transformer_kernel = nn.Parameter((torch.rand(E0, self.Dx) * 2 - 1) * lim)
             self.X0_transformer_bias = nn.Parameter(torch.zeros(self.Dx))
+
+    def sigmas(self):
+        """{distribution: scale vector} for every tf_mvn of the model.  With a flat parameter buffer
+        (optim.FlatParams) all of them come from ONE fused launch; otherwise each distribution computes its own."""
+        blk = self.__dict__.get("_sigma_block")
+        if blk is not None and blk["raw"].is_cuda:
+            from .autograd import SigmaFunction
+            sig = SigmaFunction.apply(blk, *[d.sigma_con for d in blk["dists"]])
+            return {id(d): s for d, s in zip(blk["dists"], sig.split(blk["sizes"]))}
+        out = {}
+        for mod in self.modules():
+            if isinstance(mod, tf_mvn) and id(mod) not in out:
+                out[id(mod)] = mod.get_sigma()
+        return out
 
     def X0_transformer(self, x):
         return x @ self.X0_transformer_kernel + self.X0_transformer_bias

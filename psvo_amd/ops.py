@@ -165,8 +165,8 @@ def bsim_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu
         "sel": torch.empty(T, B, N, device=dev, dtype=torch.int32), "score": torch.empty(B, N, device=dev),
         "lam2": torch.empty(T, B, N, M, device=dev) if save else None,
         "om": torch.empty(T, B, N, M, device=dev) if save else None,
-        # rows t = T-1 of mu1 are never written by the kernel (no predecessor step): keep them defined
-        "mu1": torch.zeros(T, B, Dx, N, device=dev) if save else None,
+        # (row t = T-1 of mu1 is written as zeros by the kernel: there is no predecessor step)
+        "mu1": torch.empty(T, B, Dx, N, device=dev) if save else None,
     }
     _mark("psvo_bsim_forward", 0)
     st = lib.psvo_bsim_forward(
@@ -256,7 +256,7 @@ def split_mlp_grad(g, Din, H, Dout):
 
 
 def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs, eps, filt,
-                    dlse=None, dFm=None, dlogW=None):
+                    dlse=None, dFm=None, dlogW=None, gbufs=None, before_wgrad=None):
     """psvo_filter_backward + psvo_mlp_wgrad.  `filt` = forward outputs.  dFm (T,B,Dx,N) / dlogW (T,B,N)
     are upstream gradients (or None).  Returns a dict of gradients."""
     lib = _lib.load()
@@ -283,14 +283,19 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
         _ptr(out["dfsig0"]), _ptr(sacc), _stream())
     _mark("psvo_filter_backward", 1)
     _lib.check(st, "psvo_filter_backward")
-    out["gq1"] = mlp_wgrad(filt["X"], out["dP"], q1, Dx, H, Dx)
-    out["gf"] = None if desc.bootstrap else mlp_wgrad(filt["X"], out["dF"], f, Dx, H, Dx)
-    out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy)
+    # weight gradients from rows; gbufs = (q1, f, g) slices of the flat gradient buffer to accumulate into
+    # directly (then no gradient tensor is returned for that MLP), or None
+    if before_wgrad is not None:
+        before_wgrad()
+    gb = gbufs or (None, None, None)
+    out["gq1"] = mlp_wgrad(filt["X"], out["dP"], q1, Dx, H, Dx, grad=gb[0])
+    out["gf"] = None if desc.bootstrap else mlp_wgrad(filt["X"], out["dF"], f, Dx, H, Dx, grad=gb[1])
+    out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy, grad=gb[2])
     return out
 
 
 def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig,
-                  obs, eps_b, bs, dscore):
+                  obs, eps_b, bs, dscore, gbufs=None, after_kernel=None):
     """psvo_bsim_backward + psvo_mlp_wgrad.  `bs` = bsim_forward(..., save=True) outputs."""
     lib = _lib.load()
     B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
@@ -323,14 +328,43 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
         _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(sacc), _stream())
     _mark("psvo_bsim_backward", 1)
     _lib.check(st, "psvo_bsim_backward")
-    # weight gradients from rows: MLP_f / MLP_g on the sub-particles, MLP_q1inv on bwX[t+1]
-    out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx)
-    out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy)
-    out["gq1inv"] = mlp_wgrad(bs["bwX"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx)
+    # fold the per-workgroup partials that feed the filter's reverse pass, then let the caller publish them
+    out["dFm"] = out["dFm_part"].sum(2)
+    out["dlogW"] = out["dlogW_part"].sum(2)
+    if after_kernel is not None:
+        after_kernel()
+    # weight gradients from rows: MLP_f / MLP_g on the sub-particles, MLP_q1inv on bwX[t+1];
+    # gbufs = (f, g, q1_inv) slices of the flat gradient buffer to accumulate into directly, or None
+    gb = gbufs or (None, None, None)
+    out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx, grad=gb[0])
+    out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy, grad=gb[1])
+    out["gq1inv"] = mlp_wgrad(bs["bwX"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx, grad=gb[2])
     return out
 
 
-def bilstm_backward(x, W_fw, W_bw, out, cs, gates, dout):
+def reduce_rows(part, nrows, stride, n, out, accumulate=False):
+    """psvo_reduce_rows: out[p] (+)= sum_r part[r*stride + p]; `part` may be a strided view (its data_ptr is used)."""
+    lib = _lib.load()
+    st = lib.psvo_reduce_rows(_ptr(part), nrows, stride, n, _ptr(out), int(accumulate), _stream())
+    _lib.check(st, "psvo_reduce_rows")
+    return out
+
+
+def sigma_forward(raw, mins):
+    lib = _lib.load()
+    sig = torch.empty_like(raw)
+    _lib.check(lib.psvo_sigma_forward(_ptr(raw), _ptr(mins), _ptr(sig), raw.numel(), _stream()), "psvo_sigma_forward")
+    return sig
+
+
+def sigma_backward(raw, mins, dsig, graw, accumulate=True):
+    lib = _lib.load()
+    _lib.check(lib.psvo_sigma_backward(_ptr(raw), _ptr(mins), _ptr(dsig), _ptr(graw), raw.numel(), int(accumulate),
+                                       _stream()), "psvo_sigma_backward")
+    return graw
+
+
+def bilstm_backward(x, W_fw, W_bw, out, cs, gates, dout, gbufs=None):
     """psvo_bilstm_backward -> (dx (B,T,Din), dW_fw, db_fw, dW_bw, db_bw)."""
     lib = _lib.load()
     B, T, Din = x.shape
@@ -346,6 +380,14 @@ def bilstm_backward(x, W_fw, W_bw, out, cs, gates, dout):
                                   _ptr(dout), _ptr(dx_part), _ptr(dW_part), _ptr(db_part), _stream())
     _mark("psvo_bilstm_backward", 1)
     _lib.check(st, "psvo_bilstm_backward")
+    dx = dx_part.sum(0)
+    K, G4 = Din + Dh, 4 * Dh
+    if gbufs is not None and gbufs[0] is not None and gbufs[1] is not None:
+        # fold the per-sequence partials straight into the flat gradient buffer: [kernel (K,4Dh) | bias (4Dh)]
+        for d, gb in enumerate(gbufs):
+            reduce_rows(dW_part[:, d], B, 2 * K * G4, K * G4, gb[:K * G4], accumulate=True)
+            reduce_rows(db_part[:, d], B, 2 * G4, G4, gb[K * G4:], accumulate=True)
+        return dx, None, None, None, None
     dW = dW_part.sum(0)
     db = db_part.sum(0)
-    return dx_part.sum(0), dW[0], db[0], dW[1], db[1]
+    return dx, dW[0], db[0], dW[1], db[1]

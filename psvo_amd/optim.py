@@ -28,6 +28,54 @@ class FlatParams(object):
             p.grad = self.grad[off:off + k].view_as(p.data)
             off += k
         self.numel = n
+        self._annotate(module)
+
+    def _annotate(self, module):
+        """Tell the native backward passes where each module's gradient lives in the flat buffer so they can
+        accumulate into it directly (one launch) instead of returning tensors for autograd to add one by one:
+          * one-hidden-layer MLP_transformation: [W1 | b1 | W2 | b2] -- exactly psvo_mlp_wgrad's layout;
+          * LSTMBlockCellLayer: [kernel | bias];
+          * all tf_mvn.sigma_con vectors, when contiguous: one fused softplus/clamp for every distribution."""
+        from .distribution.mvn import tf_mvn
+        from .model import LSTMBlockCellLayer
+        from .transformation.MLP import MLP_transformation
+        off, o = {}, 0
+        for q in self.params:
+            off[id(q)] = o
+            o += q.numel()
+
+        def block(ps):
+            if not all(id(q) in off for q in ps):
+                return None
+            start = off[id(ps[0])]
+            o = start
+            for q in ps:
+                if off[id(q)] != o:
+                    return None
+                o += q.numel()
+            return start, o
+
+        for mod in module.modules():
+            mod.__dict__.pop("_flat_grad", None)
+            if isinstance(mod, MLP_transformation) and len(mod.Dhs) == 1:
+                b = block([mod.kernels[0], mod.biases[0], mod.mu_kernel, mod.mu_bias])
+            elif isinstance(mod, LSTMBlockCellLayer):
+                b = block([mod.kernel, mod.bias])
+            else:
+                continue
+            if b is not None:
+                mod.__dict__["_flat_grad"] = self.grad[b[0]:b[1]]
+        dists = []
+        for mod in module.modules():
+            if isinstance(mod, tf_mvn) and all(mod is not d for d in dists):
+                dists.append(mod)
+        dists.sort(key=lambda d: off.get(id(d.sigma_con), -1))
+        b = block([d.sigma_con for d in dists]) if dists else None
+        module.__dict__["_sigma_block"] = None
+        if b is not None:
+            mins = torch.cat([torch.full((d.sigma_con.numel(),), float(d.sigma_min)) for d in dists]).to(self.flat.device)
+            module.__dict__["_sigma_block"] = {"raw": self.flat[b[0]:b[1]], "grad": self.grad[b[0]:b[1]], "mins": mins,
+                                               "dists": dists, "sizes": [d.sigma_con.numel() for d in dists]}
 
     def zero_grad(self):
         self.grad.zero_()

@@ -137,3 +137,38 @@ def test_trainer_improves_elbo(built_lib, tmp_path, monkeypatch):
     assert os.path.exists(tr.epoch_data_DIR + "metric_4.p") and os.path.exists(tr.epoch_data_DIR + "trajectory_4.p")
     Xs = tr.evaluate(log["Xs"], tr.saving_feed_dict)
     assert Xs.shape == (4, 30, 16, 2)
+
+
+@pytest.mark.parametrize("obj", ["PSVO", "SVO"])
+def test_flat_buffer_gradients_match_autograd_path(built_lib, obj):
+    """with optim.FlatParams the native backward passes accumulate straight into the flat gradient buffer
+    (and all sigmas come from one fused launch): same gradients as the plain autograd path"""
+    from psvo_amd.model import SSM
+    from psvo_amd.optim import FlatParams
+    FLAGS = Hh.make_flags(obj, n_particles=32, n_particles_for_BSim_proposal=8, batch_size=3, time=9,
+                          y_smoother_Dhs="8", X0_smoother_Dhs="8", use_bootstrap=(obj == "PSVO"))
+    torch.manual_seed(0)
+    m1 = Hh.perturb_(SSM(FLAGS)).cuda()
+    m2 = SSM(FLAGS).cuda()
+    m2.load_state_dict(m1.state_dict())
+    obs = torch.randn(3, 9, 1, generator=torch.Generator().manual_seed(2)).cuda()
+    outs = []
+    for mdl, flat in ((m1, False), (m2, True)):
+        smc = _objective(obj)(mdl, FLAGS)
+        smc.generator = torch.Generator(device="cuda").manual_seed(5)
+        fp = FlatParams(mdl) if flat else None
+        for _ in range(2):                                   # twice: accumulation into a zeroed buffer each time
+            if fp is not None:
+                fp.zero_grad()
+            else:
+                mdl.zero_grad()
+            smc.generator.manual_seed(5)
+            z, _ = smc.get_log_ZSMC(obs, None)
+            z.backward()
+        torch.cuda.synchronize()
+        outs.append((float(z.detach()), {n: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone())
+                                         for n, p in mdl.named_parameters()}))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * abs(outs[0][0])
+    for n, g in outs[0][1].items():
+        g2 = outs[1][1][n]
+        assert torch.allclose(g, g2, atol=2e-5 + 1e-4 * float(g.abs().max()), rtol=1e-3), n
