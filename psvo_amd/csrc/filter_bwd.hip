@@ -88,7 +88,8 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
     using AC = FAcc<DX, DY>;
-    constexpr bool kRolled = true;
+    // one wave per SIMD (<= 256 lanes): let the compiler keep the loop-invariant MLP weights in VGPRs
+    constexpr bool kRolled = (MAXT > 256) || (MlpLds<DX, H, DX>::kSize + MlpLds<DX, H, DY>::kSize > 330);
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -132,47 +133,48 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
     // Per-step inputs are software-prefetched: everything of step t-1 is requested at the top of step t,
     // and the ancestor index it gathers through (idx[t-2]) one step earlier still, so the dependent
     // gather Fm[t-2][idx] never sits on the critical path (two HBM round trips per step otherwise).
-    struct StepIn {
-        float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX], dfm_ext[DX];
-        float logw, lse, dlse, dlw_ext;
-        int anc;
-    };
+    // (plain arrays + scalars rather than a struct: a struct of arrays copied per step ends up in scratch)
+    float m0r[DX], fm0r[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        m0r[d] = a.m0[b * DX + d];
+        fm0r[d] = a.fm0[b * DX + d];
+    }
     auto load_anc = [&](int t) -> int {  // ancestor of particle n at step t (its parent lives at t-1)
         return (t >= 1 && a.resample) ? a.idx[((size_t)(t - 1) * B + b) * N + n] : n;
     };
-    auto load_step = [&](int t, int anc, StepIn& s) {
+    auto load_step = [&](int t, int anc, float (&sx)[DX], float (&se)[DX], float (&sm2)[DX], float (&sy)[DY],
+                         float (&smean1)[DX], float (&sfmean)[DX], float (&sdfm)[DX], float (&ssc)[4]) {
         const size_t tb = (size_t)t * B + b;
-        s.anc = anc;
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            s.x[d] = a.X[(tb * DX + d) * N + n];
-            s.e[d] = a.eps[(tb * DX + d) * N + n];
-            s.m2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
-            if (t == 0) {
-                s.mean1[d] = a.m0[b * DX + d];
-                s.fmean[d] = a.fm0[b * DX + d];
-            } else {
-                s.fmean[d] = a.Fm[((tb - B) * DX + d) * N + anc];
-                s.mean1[d] = a.bootstrap ? s.fmean[d] : a.P1[((tb - B) * DX + d) * N + anc];
-            }
+            sx[d] = a.X[(tb * DX + d) * N + n];
+            se[d] = a.eps[(tb * DX + d) * N + n];
+            sm2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
+            const size_t tp = (t == 0) ? tb : tb - B;          // (t = 0 has no parent: value replaced below)
+            const float gf = a.Fm[(tp * DX + d) * N + anc];
+            const float gp = a.bootstrap ? gf : a.P1[(tp * DX + d) * N + anc];
+            sfmean[d] = (t == 0) ? fm0r[d] : gf;
+            smean1[d] = (t == 0) ? m0r[d] : gp;
             float ext = 0.f;
             if (a.dFm_ext)
                 for (int p = 0; p < a.nparts; ++p) ext += a.dFm_ext[((tb * a.nparts + p) * DX + d) * N + n];
-            s.dfm_ext[d] = ext;
+            sdfm[d] = ext;
         }
 #pragma unroll
-        for (int k = 0; k < DY; ++k) s.y[k] = a.obs[tb * DY + k];
-        s.logw = a.logW[tb * N + n];
-        s.lse = a.lse[tb];
-        s.dlse = a.dlse ? a.dlse[tb] : 0.f;
+        for (int k = 0; k < DY; ++k) sy[k] = a.obs[tb * DY + k];
+        ssc[0] = a.logW[tb * N + n];
+        ssc[1] = a.lse[tb];
+        ssc[2] = a.dlse ? a.dlse[tb] : 0.f;
         float ext = 0.f;
         if (a.dlogW_ext)
             for (int p = 0; p < a.nparts; ++p) ext += a.dlogW_ext[(tb * a.nparts + p) * N + n];
-        s.dlw_ext = ext;
+        ssc[3] = ext;
     };
-    StepIn cur, nxt;
+    float c_x[DX], c_e[DX], c_m2[DX], c_y[DY], c_mean1[DX], c_fmean[DX], c_dfm[DX], c_sc[4];
+    int c_anc = load_anc(T - 1);
     int anc_next = load_anc(T - 2);            // ancestor used by step T-2
-    load_step(T - 1, load_anc(T - 1), cur);
+    load_step(T - 1, c_anc, c_x, c_e, c_m2, c_y, c_mean1, c_fmean, c_dfm, c_sc);
     __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
@@ -188,30 +190,33 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
         float* nxtF = accF + ((t + 1) & 1) * DX * NT;
 
         // ---- forward quantities of this step (prefetched) ----------------------------------------------
+        float n_x[DX], n_e[DX], n_m2[DX], n_y[DY], n_mean1[DX], n_fmean[DX], n_dfm[DX], n_sc[4];
+        int n_anc = n;
         if (t >= 1) {
-            load_step(t - 1, anc_next, nxt);
+            n_anc = anc_next;
+            load_step(t - 1, n_anc, n_x, n_e, n_m2, n_y, n_mean1, n_fmean, n_dfm, n_sc);
             anc_next = load_anc(t - 2);
         }
         float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX];
-        const int anc = cur.anc;
+        const int anc = c_anc;
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            x[d] = cur.x[d];
-            e[d] = cur.e[d];
-            m2[d] = cur.m2[d];
-            mean1[d] = cur.mean1[d];
-            fmean[d] = cur.fmean[d];
+            x[d] = c_x[d];
+            e[d] = c_e[d];
+            m2[d] = c_m2[d];
+            mean1[d] = c_mean1[d];
+            fmean[d] = c_fmean[d];
         }
 #pragma unroll
-        for (int k = 0; k < DY; ++k) y[k] = cur.y[k];
+        for (int k = 0; k < DY; ++k) y[k] = c_y[k];
         float mu[DX];
 #pragma unroll
         for (int d = 0; d < DX; ++d)
             mu[d] = a.two_q ? K.c[d] * fmaf(K.i1[d], mean1[d], K.i2[d] * m2[d]) : mean1[d];
 
         // ---- gradient w.r.t. logW_t[n] ------------------------------------------------------------
-        const float sm = valid ? expf(cur.logw - cur.lse) : 0.f;
-        float dlw = cur.dlse * sm + cur.dlw_ext;
+        const float sm = valid ? expf(c_sc[0] - c_sc[1]) : 0.f;
+        float dlw = c_sc[2] * sm + c_sc[3];
         if (!a.resample) {
             const float tot = block_sum(dlnw, red, wave, lane, nw);
             dlw += dlnw - sm * tot;
@@ -252,7 +257,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
         for (int d = 0; d < DX; ++d) {
             dPn[d] = curP[d * NT + tid];
             curP[d * NT + tid] = 0.f;
-            const float ext = cur.dfm_ext[d];
+            const float ext = c_dfm[d];
             if (a.bootstrap) {
                 dPn[d] += ext;
                 dFn[d] = 0.f;
@@ -318,7 +323,18 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
                 }
             }
         }
-        cur = nxt;
+        if (t >= 1) {
+            c_anc = n_anc;
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                c_x[d] = n_x[d]; c_e[d] = n_e[d]; c_m2[d] = n_m2[d];
+                c_mean1[d] = n_mean1[d]; c_fmean[d] = n_fmean[d]; c_dfm[d] = n_dfm[d];
+            }
+#pragma unroll
+            for (int k = 0; k < DY; ++k) c_y[k] = n_y[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c_sc[k] = n_sc[k];
+        }
 #pragma unroll
         for (int i = 0; i < AC::kSet; ++i) {  // set 0: t = 0, set 1: t >= 1 (static register indices)
             acc[i] += first ? inc[i] : 0.f;
