@@ -291,6 +291,17 @@ def main():
         f_dom = flops[dominant]
         achieved = units * f_dom / (k_avg * 1e-3) / 1e12
         value = world * units * args.steps / elapsed
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # figure is the committed, calibrated FETCH_SIZE / WRITE_SIZE measurement of the same workload
+        # (tools/traffic_probe.py + tools/traffic_report.py -> profiles/r01_hbm_traffic_Cstar.json), else null
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic_Cstar.json")
+        if args.workload == "C*" and os.path.exists(tp):
+            key = {"psvo_bsim_backward": "bsim_bwd_kernel", "psvo_bsim_forward": "bsim_fwd_kernel",
+                   "psvo_filter_backward": "filter_bwd_kernel", "psvo_filter_forward": "filter_fwd_kernel"}[dominant]
+            for k, v in json.load(open(tp))["kernels"].items():
+                if key in k:
+                    traffic, traffic_src = v["hbm_MB_per_launch"] * 1e6, "profiles/r01_hbm_traffic_Cstar.json"
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -305,7 +316,8 @@ def main():
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)",
+                         "traffic_source": traffic_src,
                          "kernel": dominant, "kernel_ms_avg": k_avg, "flop_per_particle_step": f_dom,
                          "exp_frac": (units * x_bsim / (k_avg * 1e-3) / EXP_PEAK) if "bsim" in dominant else None,
                          "note": "fp32 VALU + transcendental work, not GEMM-shaped (K = Dx <= 4): priced against the "

@@ -152,14 +152,14 @@ int psvo_bsim_forward(const psvo_desc* desc,
  *            dscore (B,N) = d loss / d score.
  *  outputs : rows for psvo_mlp_wgrad: xt (T,B,Dx,N,M) sub-particles, dFt (T,B,Dx,N,M) w.r.t.
  *            MLP_f(x~), dGt (T,B,Dy,N,M) w.r.t. MLP_g(x~), dmu1 (T,B,Dx,N) w.r.t. MLP_q1inv(bwX[t+1]);
- *            per-workgroup partials (nblk = psvo_bsim_blocks(B, N, M, H), to be summed over that axis):
+ *            per-workgroup partials (nblk = psvo_bsim_blocks(B, N, M, H, Dx), to be summed over that axis):
  *            dFm_part (T,B,nblk,Dx,N), dlogW_part (T,B,nblk,N)  -> psvo_filter_backward,
  *            dbmu2_part (T,B,nblk,Dx), dminit_part (B,nblk,Dx), dimean_part (B,nblk,Dx);
  *            scale gradients dsig_f, dsig_q1inv, dsig_bq2, dsig_init, disig (Dx), dsig_g (Dy).
  *  sacc_part: workspace, B * nblk * psvo_bsim_acc_size(Dx, Dy) floats.
  *  The gradient w.r.t. lse is identically zero (the normalised weights' gradients sum to zero).
  * ------------------------------------------------------------------------------------------- */
-int psvo_bsim_blocks(int B, int N, int M, int H);
+int psvo_bsim_blocks(int B, int N, int M, int H, int Dx);
 int psvo_bsim_acc_size(int Dx, int Dy);
 int psvo_bsim_backward(const psvo_desc* desc,
                        const float* Fm, const float* logW, const float* lse,

@@ -44,7 +44,7 @@ SIGNATURES = {
     "psvo_mlp_wgrad": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       _P, _P, _MLP, _P, _P, ctypes.c_int, _P]),
     "psvo_bsim_forward": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 22 + [_P]),
-    "psvo_bsim_blocks": (ctypes.c_int, [ctypes.c_int] * 4),
+    "psvo_bsim_blocks": (ctypes.c_int, [ctypes.c_int] * 5),
     "psvo_bsim_acc_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "psvo_bsim_backward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 34),
     "psvo_bilstm_forward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 8 + [_P]),

@@ -8,9 +8,9 @@ extern template int bb_dispatch_dy<3>(const BsimBwdArgs&, const BsimBwdOut&, int
 extern template int bb_dispatch_dy<4>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
 }  // namespace psvo
 
-extern "C" int psvo_bsim_blocks(int B, int N, int M, int H) {
+extern "C" int psvo_bsim_blocks(int B, int N, int M, int H, int Dx) {
     int HS, NTB, cpb, nblk;
-    psvo::bsim_geometry(B, N, M, H, HS, NTB, cpb, nblk);
+    psvo::bsim_geometry(B, N, M, H, Dx, HS, NTB, cpb, nblk);
     return nblk;
 }
 

@@ -615,10 +615,12 @@ struct BsimBwdOut {
     float *dsig_f, *dsig_g, *dsig_q1inv, *dsig_bq2, *dsig_init, *disig;
 };
 
-static inline void bsim_geometry(int B, int N, int M, int H, int& HS, int& NTB, int& cpb, int& nblk) {
-    // fewer than two waves per SIMD (1024 SIMDs) with one lane per (chain, m): spread a chain over 2M lanes
+static inline void bsim_geometry(int B, int N, int M, int H, int Dx, int& HS, int& NTB, int& cpb, int& nblk) {
+    // fewer than two waves per SIMD (1024 SIMDs) with one lane per (chain, m): spread a chain over 2M lanes.
+    // Only for Dx <= 2: two waves per SIMD need <= 256 VGPRs, which the Dx >= 3 reverse kernel exceeds
+    // (measured: 264-1056 B/lane of scratch when forced), and a spilling kernel is slower than a lone wave.
     const long long waves1 = ((long long)B * N * M + 63) / 64;
-    HS = (waves1 < 2048 && 2 * M <= 64 && (H / 2) % 4 == 0) ? 2 : 1;
+    HS = (waves1 < 2048 && 2 * M <= 64 && (H / 2) % 4 == 0 && Dx <= 2) ? 2 : 1;
     NTB = ((N * M * HS + 63) / 64) * 64;
     if (NTB > 256) NTB = 256;
     cpb = NTB / (M * HS);
@@ -633,7 +635,7 @@ static int launch_bsim_bwd(const BsimBwdArgs& a, const BsimBwdOut& o, hipStream_
     constexpr int PS = BTileSlot<DX>::kFloats;
     const int NP = (a.N + 3) & ~3;
     int HS, NTB, cpb, nblk;
-    bsim_geometry(a.B, a.N, M, H, HS, NTB, cpb, nblk);
+    bsim_geometry(a.B, a.N, M, H, DX, HS, NTB, cpb, nblk);
     const int nwv = NTB / 64;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nwv * (DX + 1) * NP +
                                         2 * cpb * DX + 16);
@@ -641,12 +643,9 @@ static int launch_bsim_bwd(const BsimBwdArgs& a, const BsimBwdOut& o, hipStream_
     // chunk of forward-tile entries reduced in registers per butterfly: 32 when a lane walks >= 32 entries
     const int walk = (NP / 4 + HS - 1) / HS;
     if (HS == 2) {
-        if constexpr (2 * M <= 64 && (H / 2) % 4 == 0) {
-            if (walk >= 32)
-                hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 32, 2>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
-            else
-                hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 16, 2>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
-        }
+        // chunks of 8 entries keep the half-split kernel at 251 VGPRs (two waves per SIMD, no scratch)
+        if constexpr (2 * M <= 64 && (H / 2) % 4 == 0 && DX <= 2)
+            hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 8, 2>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
     } else if (walk >= 32) {
         hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 32, 1>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
     } else {

@@ -34,7 +34,7 @@ def test_version_and_status_strings(built_lib):
     assert lib.psvo_status_string(0) == b"ok"
     assert b"unsupported" in lib.psvo_status_string(_lib.PSVO_ERR_UNSUPPORTED)
     assert lib.psvo_filter_acc_size(2, 1) == 21 and lib.psvo_bsim_acc_size(3, 2) == 23
-    assert lib.psvo_bsim_blocks(32, 128, 16, 32) == 16 and lib.psvo_bsim_blocks(64, 256, 16, 32) == 16 and lib.psvo_bsim_blocks(2, 8, 4, 16) == 1
+    assert lib.psvo_bsim_blocks(32, 128, 16, 32, 2) == 16 and lib.psvo_bsim_blocks(32, 128, 16, 32, 3) == 8 and lib.psvo_bsim_blocks(2, 8, 4, 16, 2) == 1
     assert lib.psvo_mlp_wgrad_blocks(10) == 1 and lib.psvo_mlp_wgrad_blocks(10 ** 9) == 1024
 
 
