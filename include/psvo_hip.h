@@ -261,6 +261,10 @@ int psvo_sigma_forward(const float* raw, const float* mins, float* sig, int n, v
 int psvo_sigma_backward(const float* raw, const float* mins, const float* dsig, float* graw, int n,
                         int accumulate, void* stream);
 
+/* Diagnostic: runs the DPP / permlane cross-lane primitives the kernels are built on over one
+ * wavefront of input (64 floats) and writes 9 x 64 results (xor 1..32, inclusive scan, sum, max). */
+int psvo_selftest_lanes(const float* in64, float* out576, void* stream);
+
 /* Per-sequence ELBO reductions (no batch mean: the caller averages, so a batch shard can be
  * all-reduced).  filter: out[b] = sum_t lse[t,b] (SVO.compute_log_ZSMC, SVO.py:302-311);
  * bsim: out[b] = logsumexp_n score[b,n] - log N (PSVO.compute_log_ZSMC, PSVO.py:52-67). */

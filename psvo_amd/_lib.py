@@ -54,6 +54,7 @@ SIGNATURES = {
     "psvo_reduce_rows": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, _P, ctypes.c_int, _P]),
     "psvo_sigma_forward": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P]),
     "psvo_sigma_backward": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
+    "psvo_selftest_lanes": (ctypes.c_int, [_P, _P, _P]),
     "psvo_elbo_filter": (ctypes.c_int, [_DESC, _P, _P, _P]),
     "psvo_elbo_bsim": (ctypes.c_int, [_DESC, _P, _P, _P]),
 }

@@ -126,3 +126,31 @@ extern "C" int psvo_sigma_backward(const float* raw, const float* mins, const fl
                        mins, dsig, graw, n, accumulate);
     return psvo::launch_status();
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// on-device self-test of the cross-lane primitives in common.h (tests/test_gpu_parity.py)
+// out rows: xor 1,2,4,8,16,32 | inclusive scan | sum | max   -> 9 x 64 floats
+// ---------------------------------------------------------------------------------------------
+namespace psvo {
+__global__ void lane_selftest_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    const int l = threadIdx.x;
+    const float v = in[l];
+    out[0 * 64 + l] = xor_lane<1>(v);
+    out[1 * 64 + l] = xor_lane<2>(v);
+    out[2 * 64 + l] = xor_lane<4>(v);
+    out[3 * 64 + l] = xor_lane<8>(v);
+    out[4 * 64 + l] = xor_lane<16>(v);
+    out[5 * 64 + l] = xor_lane<32>(v);
+    out[6 * 64 + l] = wave_incl_scan(v, l);
+    out[7 * 64 + l] = wave_sum(v);
+    out[8 * 64 + l] = wave_max(v);
+}
+}  // namespace psvo
+
+extern "C" int psvo_selftest_lanes(const float* in64, float* out576, void* stream) {
+    if (!in64 || !out576) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
+    hipLaunchKernelGGL(psvo::lane_selftest_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in64, out576);
+    return psvo::launch_status();
+}

@@ -77,8 +77,8 @@ __device__ __forceinline__ void read_slot(const float* p, float (&F)[DX], float&
 
 // One butterfly stage of the reduce-scatter over quads: the NN live entries are halved; the lane
 // keeps the half selected by its `bit` and adds the partner's (lane ^ mask) copy of that half.
-template <int CH, int NA, int NN>
-__device__ __forceinline__ void rs_stage(float (&A)[CH][NA], int bit, int mask) {
+template <int CH, int NA, int NN, int MASK>
+__device__ __forceinline__ void rs_stage(float (&A)[CH][NA], int bit) {
 #pragma unroll
     for (int i = 0; i < NN / 2; ++i) {
 #pragma unroll
@@ -86,7 +86,7 @@ __device__ __forceinline__ void rs_stage(float (&A)[CH][NA], int bit, int mask) 
             const float lo = A[i][d], hi = A[i + NN / 2][d];
             const float send = bit ? lo : hi;
             const float keep = bit ? hi : lo;
-            A[i][d] = keep + __shfl_xor(send, mask);
+            A[i][d] = keep + xor_lane<MASK>(send);
         }
     }
 }
@@ -296,13 +296,15 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 #endif
             const float lam2 = cur_in.lam2;
             float xq[4][DX], lq[4], dl[4], U[4][DX], V[4][DX];
+            quad_bcast4(lam2, lq);
+            quad_bcast4(dlam, dl);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lq[i] = quad_bcast_b(lam2, lane, i);
-                dl[i] = quad_bcast_b(dlam, lane, i);
+            for (int d = 0; d < DX; ++d) {
+                float t4[4];
+                quad_bcast4(x[d] * rp[d], t4);
 #pragma unroll
-                for (int d = 0; d < DX; ++d) {
-                    xq[i][d] = quad_bcast_b(x[d] * rp[d], lane, i);
+                for (int i = 0; i < 4; ++i) {
+                    xq[i][d] = t4[i];
                     U[i][d] = 0.f;
                     V[i][d] = 0.f;
                 }
@@ -345,13 +347,13 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                     }
                 }
                 constexpr int b0 = stage_bit<M, HS>(0), b1 = stage_bit<M, HS>(1), b2 = stage_bit<M, HS>(2);
-                rs_stage<CH, NA, CH>(A, (lane >> b0) & 1, 1 << b0);
-                rs_stage<CH, NA, CH / 2>(A, (lane >> b1) & 1, 1 << b1);
-                rs_stage<CH, NA, CH / 4>(A, (lane >> b2) & 1, 1 << b2);
+                rs_stage<CH, NA, CH, (1 << b0)>(A, (lane >> b0) & 1);
+                rs_stage<CH, NA, CH / 2, (1 << b1)>(A, (lane >> b1) & 1);
+                rs_stage<CH, NA, CH / 4, (1 << b2)>(A, (lane >> b2) & 1);
                 int ebase = ((lane >> b0) & 1) * (CH / 2) + ((lane >> b1) & 1) * (CH / 4) + ((lane >> b2) & 1) * (CH / 8);
                 if constexpr (NS == 4) {
                     constexpr int b3 = stage_bit<M, HS>(3);
-                    rs_stage<CH, NA, CH / 8>(A, (lane >> b3) & 1, 1 << b3);
+                    rs_stage<CH, NA, CH / 8, (1 << b3)>(A, (lane >> b3) & 1);
                     ebase += ((lane >> b3) & 1) * (CH / 16);
                 }
                 constexpr int R = CH >> NS;
@@ -376,10 +378,8 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
                     float u = U[i][d], v = V[i][d];
-                    u += __shfl_xor(u, 1);
-                    u += __shfl_xor(u, 2);
-                    v += __shfl_xor(v, 1);
-                    v += __shfl_xor(v, 2);
+                    u = group_sum<4>(u);
+                    v = group_sum<4>(v);
                     if (i == q) {
                         Uo[d] = u;
                         Vo[d] = v;
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                 } else {
                     MQ::template eval_part<HS>(wf, hpart, x, fmx);
 #pragma unroll
-                    for (int d = 0; d < DX; ++d) fmx[d] += __shfl_xor(fmx[d], M);
+                    for (int d = 0; d < DX; ++d) fmx[d] += xor_lane<M>(fmx[d]);
                 }
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
             } else {
                 MG::template eval_part<HS>(wg, hpart, x, gm);
 #pragma unroll
-                for (int k = 0; k < DY; ++k) gm[k] += __shfl_xor(gm[k], M);
+                for (int k = 0; k < DY; ++k) gm[k] += xor_lane<M>(gm[k]);
             }
 #pragma unroll
             for (int k = 0; k < DY; ++k) {
@@ -467,17 +467,11 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         for (int d = 0; d < DX; ++d) {
             float v0 = dxt[d], v1 = dxt[d] * eps[d], v2 = dxp_part[d];
             float v3 = (first && h0) ? dphi * (x[d] - im[d]) * i_isig[d] * i_isig[d] : 0.f;
-#pragma unroll
-            for (int o = 1; o < G; o <<= 1) {  // over the M sub-particles and the HS halves
-                v0 += __shfl_xor(v0, o);
-                v1 += __shfl_xor(v1, o);
-                v2 += __shfl_xor(v2, o);
-                v3 += __shfl_xor(v3, o);
-            }
-            dmu[d] = v0;
-            sce[d] = v1;
-            dxp[d] = v2;
-            dim[d] = v3;
+            // over the M sub-particles and the HS halves
+            dmu[d] = group_sum<G>(v0);
+            sce[d] = group_sum<G>(v1);
+            dxp[d] = group_sum<G>(v2);
+            dim[d] = first ? group_sum<G>(v3) : 0.f;
         }
         const bool lead = (m == 0) && h0 && valid;
         float outv[DX];  // per-chain value that is summed over the workgroup: d bmu2 / d minit
@@ -503,7 +497,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                 for (int d = 0; d < DX; ++d) dq[d] = 0.f;
                 MQ::template bwd_input_part<HS>(wqi, hpart, xp, dmu1, dq);
 #pragma unroll
-                for (int d = 0; d < DX; ++d) dxp[d] += dq[d] + __shfl_xor(dq[d], M);
+                for (int d = 0; d < DX; ++d) dxp[d] += dq[d] + xor_lane<M>(dq[d]);
             }
         } else {
 #pragma unroll

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
             } else {
                 MQ::template eval_part<HS>(wqi, hpart, xp, m1);
 #pragma unroll
-                for (int d = 0; d < DX; ++d) m1[d] += __shfl_xor(m1[d], M);
+                for (int d = 0; d < DX; ++d) m1[d] += xor_lane<M>(m1[d]);
             }
             if (a.mu1_all && valid && lead) {
 #pragma unroll
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
             } else {
                 MQ::template eval_part<HS>(wf, hpart, x, fmx);
 #pragma unroll
-                for (int d = 0; d < DX; ++d) fmx[d] += __shfl_xor(fmx[d], M);
+                for (int d = 0; d < DX; ++d) fmx[d] += xor_lane<M>(fmx[d]);
             }
             phi = diag_lp<DX>(xp, fmx, isf, kf);
         }
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         } else {
             MG::template eval_part<HS>(wg, hpart, x, gm);
 #pragma unroll
-            for (int k = 0; k < DY; ++k) gm[k] += __shfl_xor(gm[k], M);
+            for (int k = 0; k < DY; ++k) gm[k] += xor_lane<M>(gm[k]);
         }
         const float g_lp = diag_lp<DY>(obs_c, gm, isg, kg);
 
@@ -269,9 +269,12 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         if (t >= 1) {
             float xq[4][DX];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int d = 0; d < DX; ++d) {
+                float t4[4];
+                quad_bcast4(x[d] * rp[d], t4);
 #pragma unroll
-                for (int d = 0; d < DX; ++d) xq[i][d] = quad_bcast(x[d] * rp[d], lane, i);
+                for (int i = 0; i < 4; ++i) xq[i][d] = t4[i];
+            }
             float mx[4], sm[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -359,8 +362,8 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float mm = mx[i], ss = sm[i];
-                lse2_merge(mm, ss, __shfl_xor(mx[i], 1), __shfl_xor(sm[i], 1));
-                const float m2 = __shfl_xor(mm, 2), s2 = __shfl_xor(ss, 2);
+                lse2_merge(mm, ss, xor_lane<1>(mx[i]), xor_lane<1>(sm[i]));
+                const float m2 = xor_lane<2>(mm), s2 = xor_lane<2>(ss);
                 lse2_merge(mm, ss, m2, s2);
                 if (i == q) {
                     lm = mm;
@@ -368,7 +371,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
                 }
             }
             if constexpr (HS == 2) {  // the other half of the chain walked the other forward particles
-                const float m2 = __shfl_xor(lm, M), s2 = __shfl_xor(ls, M);
+                const float m2 = xor_lane<M>(lm), s2 = xor_lane<M>(ls);
                 lse2_merge(lm, ls, m2, s2);
             }
             const float lam2 = lm + log2_fast(ls);
@@ -380,16 +383,9 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
 
         // ---- omega, normalise over the M sub-particles, draw one ---------------------------------------
         const float om_raw = lam + phi + g_lp - q_lp;
-        float omx = om_raw;
-#pragma unroll
-        for (int o = 1; o < M; o <<= 1) omx = fmaxf(omx, __shfl_xor(omx, o));
+        const float omx = group_max<M>(om_raw);
         const float pw = expf(om_raw - omx);
-        float cdfv = pw;  // inclusive scan across the chain's M lanes
-#pragma unroll
-        for (int o = 1; o < M; o <<= 1) {
-            const float tv = __shfl_up(cdfv, o);
-            if (m >= o) cdfv += tv;
-        }
+        const float cdfv = group_incl_scan<M>(pw, m);  // inclusive scan across the chain's M lanes
         const float total = __shfl(cdfv, gbase + M - 1);
         const float omega = om_raw - (omx + logf(total));
         if (a.om_all && valid && hpart == 0) a.om_all[(tb * N + n) * M + m] = omega;

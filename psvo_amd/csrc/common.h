@@ -213,25 +213,110 @@ __device__ __forceinline__ float diag_lp(const float (&x)[D], const float (&mu)[
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave / block collectives (wave = 64 lanes)
+// cross-lane primitives (wave = 64 lanes) on the VALU: DPP row / quad controls and the gfx950
+// v_permlane{16,32}_swap instead of ds_bpermute (LDS crossbar, ~100+ cycles of exposed latency per
+// dependent step when a SIMD holds one or two waves, which is the regime of every kernel here).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = false>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                  CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+
+// value of lane (l ^ MASK), MASK a power of two < 64
+template <int MASK>
+__device__ __forceinline__ float xor_lane(float v) {
+    static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8 || MASK == 16 || MASK == 32, "xor_lane mask");
+    if constexpr (MASK == 1) {
+        return dpp_mov<0xB1>(v, v);                      // quad_perm [1,0,3,2]
+    } else if constexpr (MASK == 2) {
+        return dpp_mov<0x4E>(v, v);                      // quad_perm [2,3,0,1]
+    } else if constexpr (MASK == 4) {
+        float t = dpp_mov<0x104, 0xF, 0x5>(v, v);        // banks 0,2 <- lane + 4   (row_shl:4)
+        return dpp_mov<0x114, 0xF, 0xA>(t, v);           // banks 1,3 <- lane - 4   (row_shr:4)
+    } else if constexpr (MASK == 8) {
+        return dpp_mov<0x128>(v, v);                     // row_ror:8
+    } else if constexpr (MASK == 16) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        const bool odd_row = (__lane_id() >> 4) & 1;
+        return __builtin_bit_cast(float, odd_row ? p[0] : p[1]);
+    } else {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __builtin_bit_cast(float, (__lane_id() >= 32) ? p[0] : p[1]);
+    }
+}
+
+// inclusive prefix sum over the wave (classic 7-step DPP scan; lane 63 ends up with the total)
+__device__ __forceinline__ float wave_incl_scan(float v, int /*lane*/) {
+    v += dpp_mov<0x111, 0xF, 0xF, true>(0.f, v);        // row_shr:1
+    v += dpp_mov<0x112, 0xF, 0xF, true>(0.f, v);        // row_shr:2
+    v += dpp_mov<0x114, 0xF, 0xF, true>(0.f, v);        // row_shr:4
+    v += dpp_mov<0x118, 0xF, 0xF, true>(0.f, v);        // row_shr:8
+    v += dpp_mov<0x142, 0xA, 0xF, false>(0.f, v);       // row_bcast:15 -> rows 1, 3
+    v += dpp_mov<0x143, 0xC, 0xF, false>(0.f, v);       // row_bcast:31 -> rows 2, 3
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_incl_scan(v, 0);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    const float ninf = -__builtin_huge_valf();
+    v = fmaxf(v, dpp_mov<0x111>(ninf, v));
+    v = fmaxf(v, dpp_mov<0x112>(ninf, v));
+    v = fmaxf(v, dpp_mov<0x114>(ninf, v));
+    v = fmaxf(v, dpp_mov<0x118>(ninf, v));
+    v = fmaxf(v, dpp_mov<0x142, 0xA>(ninf, v));
+    v = fmaxf(v, dpp_mov<0x143, 0xC>(ninf, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// the four lanes of each quad broadcast to all of them: out[i] = value of quad lane i
+__device__ __forceinline__ void quad_bcast4(float v, float (&out)[4]) {
+    out[0] = dpp_mov<0x00>(v, v);
+    out[1] = dpp_mov<0x55>(v, v);
+    out[2] = dpp_mov<0xAA>(v, v);
+    out[3] = dpp_mov<0xFF>(v, v);
+}
+
+// all-reduce over aligned groups of G lanes (G a power of two <= 64)
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (G > 1) v += xor_lane<1>(v);
+    if constexpr (G > 2) v += xor_lane<2>(v);
+    if constexpr (G > 4) v += xor_lane<4>(v);
+    if constexpr (G > 8) v += xor_lane<8>(v);
+    if constexpr (G > 16) v += xor_lane<16>(v);
+    if constexpr (G > 32) v += xor_lane<32>(v);
     return v;
 }
-__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+    if constexpr (G > 1) v = fmaxf(v, xor_lane<1>(v));
+    if constexpr (G > 2) v = fmaxf(v, xor_lane<2>(v));
+    if constexpr (G > 4) v = fmaxf(v, xor_lane<4>(v));
+    if constexpr (G > 8) v = fmaxf(v, xor_lane<8>(v));
+    if constexpr (G > 16) v = fmaxf(v, xor_lane<16>(v));
+    if constexpr (G > 32) v = fmaxf(v, xor_lane<32>(v));
     return v;
+}
+// inclusive prefix sum inside aligned groups of G lanes; `m` = lane index inside its group
+template <int G>
+__device__ __forceinline__ float group_incl_scan(float v, int m) {
+    if constexpr (G > 1) { const float t = dpp_mov<0x111, 0xF, 0xF, true>(0.f, v); v += (m >= 1) ? t : 0.f; }
+    if constexpr (G > 2) { const float t = dpp_mov<0x112, 0xF, 0xF, true>(0.f, v); v += (m >= 2) ? t : 0.f; }
+    if constexpr (G > 4) { const float t = dpp_mov<0x114, 0xF, 0xF, true>(0.f, v); v += (m >= 4) ? t : 0.f; }
+    if constexpr (G > 8) { const float t = dpp_mov<0x118, 0xF, 0xF, true>(0.f, v); v += (m >= 8) ? t : 0.f; }
+    // groups wider than a 16-lane row: add the running total of the previous row(s) (its last lane)
+    if constexpr (G > 16) v += dpp_mov<0x142, 0xA, 0xF, false>(0.f, v);   // row_bcast:15 -> rows 1, 3
+    if constexpr (G > 32) v += dpp_mov<0x143, 0xC, 0xF, false>(0.f, v);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// value of lane `src` (wave-uniform index) in every lane
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
 
 // block-wide max / sum over `nw` waves; `red` is >= 2*16 floats of LDS scratch.

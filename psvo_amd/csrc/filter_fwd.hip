@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
             sc += off;
             total = tot;
         } else {
-            total = __shfl(sc, 63);
+            total = lane_bcast(sc, 63);
         }
         const float lse_t = mx + logf(total);
         if (tid == 0) a.lse[tb] = lse_t;

@@ -214,3 +214,23 @@ def test_filter_gradients(built_lib, case):
     torch.cuda.synchronize()
     assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
     _check_grads(model, P)
+
+
+def test_cross_lane_primitives(built_lib):
+    """DPP / v_permlane*_swap helpers of csrc/common.h against their definitions"""
+    import ctypes
+    from psvo_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, generator=g)
+    xin, out = x.cuda(), torch.empty(9 * 64, device="cuda")
+    st = lib.psvo_selftest_lanes(ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(st, "psvo_selftest_lanes")
+    out = out.cpu().view(9, 64)
+    lanes = torch.arange(64)
+    for r, m in enumerate((1, 2, 4, 8, 16, 32)):
+        assert torch.equal(out[r], x[lanes ^ m]), "xor_lane<%d>" % m
+    assert torch.allclose(out[6], torch.cumsum(x.double(), 0).float(), atol=1e-5)
+    assert torch.allclose(out[7], x.double().sum().float().expand(64), atol=1e-5)
+    assert torch.equal(out[8], x.max().expand(64))
