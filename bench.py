@@ -133,8 +133,8 @@ def cpu_baseline(wl, P, obs_cpu, sample_T, threads, train):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C*", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
