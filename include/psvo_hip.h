@@ -178,6 +178,63 @@ int psvo_bsim_backward(const psvo_desc* desc,
                        float* disig, float* sacc_part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * PSVOwR: backward simulation with cross-chain resampling and a per-step ELBO.
+ * Replaces PSVOwR.backward_simulation_w_resampling (reference src/SMC/PSVOwR.py:65-198), called from
+ * PSVOwR.get_log_ZSMC (src/SMC/PSVOwR.py:38-62).  One persistent workgroup per sequence.
+ *
+ *  inputs  : as psvo_bsim_forward (the filter's Fm, logW, lse; the hoisted backward-proposal inputs),
+ *            plus  u_r (T,B,N) uniforms of the cross-chain multinomial draw (or NULL with anc_in)
+ *                  anc_in (T,B,N) teacher-forced cross-chain ancestors (NULL = draw from u_r).
+ *            The reference resamples after every step including t = 0 (PSVOwR.py:150-160, 187-196).
+ *  outputs : bwX    (T,B,Dx,N) selected sub-particle of every chain before the cross-chain draw
+ *            bwXanc (T,B,Dx,N) the resampled chains, bwXanc[t][k] = bwX[t][anc[t][k]]  (the returned
+ *                              trajectories bw_Xs, PSVOwR.py:198)
+ *            bwW    (T,B,N)    bw_log_W of the step (PSVOwR.py:135-142), lseW (T,B) = logsumexp_n bwW
+ *                              (ELBO = sum_t lseW[t] - T log N, PSVOwR.py:144-148, 184-185)
+ *            sel_out, anc_out (T,B,N) drawn sub-particle / cross-chain ancestor indices
+ *            lam2_all (T,B,N,M), om_all (T,B,N,M), mu1_all (T,B,Dx,N): optional saves for
+ *            psvo_bsimwr_backward.
+ * ------------------------------------------------------------------------------------------- */
+int psvo_bsimwr_forward(const psvo_desc* desc,
+                        const float* Fm, const float* logW, const float* lse,
+                        const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
+                        const float* sig_f, const float* sig_g, const float* sig_q1inv, const float* sig_bq2,
+                        const float* bmu2, const float* minit, const float* sig_init,
+                        const float* imean, const float* isig,
+                        const float* obs, const float* eps_b, const float* u_b, const float* u_r,
+                        const int32_t* sel_in, const int32_t* anc_in,
+                        float* bwX, float* bwXanc, float* bwW, float* lseW,
+                        int32_t* sel_out, int32_t* anc_out,
+                        float* lam2_all, float* om_all, float* mu1_all,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reverse mode of psvo_bsimwr_forward (TensorFlow autodiff of the loop above, src/trainer.py:115-118).
+ *  inputs  : the forward call's inputs and outputs (all three saves required) and dlseW (T,B) =
+ *            d loss / d lseW.
+ *  outputs : rows for psvo_mlp_wgrad: xt, dFt (T,B,Dx,N,M), dGt (T,B,Dy,N,M), dmu1 (T,B,Dx,N) w.r.t.
+ *            MLP_q1inv(bwXanc[t+1]);  dFm (T,B,Dx,N), dlogW (T,B,N), dlse (T,B) -> psvo_filter_backward
+ *            (complete, no partial axis; here the gradient w.r.t. the filter's lse is NOT zero);
+ *            dbmu2 (T,B,Dx), dminit (B,Dx), dimean (B,Dx); scale gradients as psvo_bsim_backward.
+ *  sacc    : workspace, B * psvo_bsim_acc_size(Dx, Dy) floats.
+ * ------------------------------------------------------------------------------------------- */
+int psvo_bsimwr_backward(const psvo_desc* desc,
+                         const float* Fm, const float* logW, const float* lse,
+                         const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
+                         const float* sig_f, const float* sig_g, const float* sig_q1inv, const float* sig_bq2,
+                         const float* bmu2, const float* minit, const float* sig_init,
+                         const float* imean, const float* isig,
+                         const float* obs, const float* eps_b,
+                         const float* bwXanc, const float* bwW, const float* lseW,
+                         const int32_t* sel, const int32_t* anc,
+                         const float* lam2_all, const float* om_all, const float* mu1_all,
+                         const float* dlseW,
+                         float* xt, float* dFt, float* dGt, float* dmu1,
+                         float* dFm, float* dlogW, float* dlse, float* dbmu2, float* dminit, float* dimean,
+                         float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
+                         float* disig, float* sacc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Reverse mode of psvo_filter_forward.  The reference obtains these gradients from TensorFlow
  * autodiff of the tf.while_loop (reference src/trainer.py:115-118; no stop_gradient in src/,
  * SURVEY.md Appendix B).  One persistent workgroup per sequence walks t = T-1 .. 0.

@@ -501,6 +501,8 @@ def make_noise(flags, B, T, seed=1234, dtype=torch.float64):
         M = flags["n_particles_for_BSim_proposal"]
         noise["eps_b"] = torch.randn(T, M, N, B, Dx, generator=gen, dtype=torch.float64).to(dtype)
         noise["u_b"] = torch.rand(T, N, B, generator=gen, dtype=torch.float64).to(dtype)
+    if flags.get("objective") == "PSVOwR":
+        noise["u_r"] = torch.rand(T, N, B, generator=gen, dtype=torch.float64).to(dtype)
     return noise
 
 
@@ -537,3 +539,104 @@ def fhn_synthetic(n, T, seed=0, dt=0.15, obs_cov=0.01, dtype=torch.float64):
     hidden = torch.stack(xs, 1)
     obs = hidden[..., :1] + math.sqrt(obs_cov) * torch.randn(n, T, 1, generator=gen, dtype=torch.float64)
     return hidden.to(dtype), obs.to(dtype)
+
+
+class OraclePSVOwR(OraclePSVO):
+    """PSVOwR -- src/SMC/PSVOwR.py:8-211: PSVO whose backward chains are additionally resampled
+    across the particle axis every step, with a per-step ELBO.
+
+    Extra noise: u_r (T, N, B) uniforms (or idx_r (T, N, B) teacher-forced ancestors) for the
+    cross-chain multinomial draw (PSVOwR.py:103,145,185)."""
+
+    @staticmethod
+    def compute_log_ZSMC_wr(bw_log_W):                     # PSVOwR.py:52-63
+        N = bw_log_W.shape[1]
+        return (logsumexp(bw_log_W, 1) - math.log(float(N))).sum(0).mean()
+
+    def backward_simulation_w_proposal(self, Xs, log_Ws, obs, noise):   # PSVOwR.py:65-198
+        T, N, B, Dx = Xs.shape
+        M = self.M
+        eps, u, idx_tf = noise["eps_b"], noise.get("u_b"), noise.get("idx_b")
+        u_r, idx_r = noise.get("u_r"), noise.get("idx_r")
+        logM = math.log(float(M))
+        _, enc = self.BS_preprocess_obs(obs)
+
+        def pick(t):
+            return (None if u is None else u[t]), (None if idx_tf is None else idx_tf[t])
+
+        def pick_r(t):
+            return (None if u_r is None else u_r[t]), (None if idx_r is None else idx_r[t])
+
+        def filter_term(x_t, tm1):
+            tiled = x_t.unsqueeze(2).expand(M, N, N, B, Dx)
+            f_tm1 = self.f.log_prob(Xs[tm1], tiled)
+            log_W_tm1 = log_Ws[tm1] - logsumexp(log_Ws[tm1], 0)
+            return logsumexp(f_tm1 + log_W_tm1, 2)
+
+        bw_Xs, bw_Xanc, bw_W, sels, ancs = [None] * T, [None] * T, [None] * T, [None] * T, [None] * T
+
+        # t = T-1 (PSVOwR.py:77-104)
+        t = T - 1
+        x, q_lp = self.BSim_q_init.sample_and_log_prob(enc[t], eps[t])
+        Lam = filter_term(x, t - 1)
+        g_lp = self.g.log_prob(x, obs[:, t])
+        omega = Lam + g_lp - q_lp
+        omega = omega - logsumexp(omega, 0, keepdim=True)
+        W = Lam + g_lp - q_lp - omega - logM
+        ut, it = pick(t)
+        (x, W, omega), sel = self.resample_X([x, W, omega], omega, u=ut, idx=it, sample_size=())
+        ur, ir = pick_r(t)
+        x_anc, anc = self.resample_X(x, omega, u=ur, idx=ir, sample_size=N)
+        bw_Xs[t], bw_W[t], bw_Xanc[t], sels[t], ancs[t] = x, W, x_anc, sel, anc
+
+        # t = T-2 .. 1 (PSVOwR.py:113-149)
+        for t in range(T - 2, 0, -1):
+            x_tp1 = bw_Xanc[t + 1]
+            x, q_lp, _ = self.sample_from_2_dist(self.q1_inv, self.BSim_q2, x_tp1, enc[t], eps[t])
+            f_lp = self.f.log_prob(x, x_tp1)
+            Lam = filter_term(x, t - 1)
+            g_lp = self.g.log_prob(x, obs[:, t])
+            omega = Lam + f_lp + g_lp - q_lp
+            omega = omega - logsumexp(omega, 0)
+            W = Lam + g_lp
+            ut, it = pick(t)
+            (x, omega, W, q_lp), sel = self.resample_X([x, omega, W, q_lp], omega, u=ut, idx=it, sample_size=())
+            W = W - (q_lp + omega + logM)
+            ur, ir = pick_r(t)
+            x_anc, anc = self.resample_X(x, omega, u=ur, idx=ir, sample_size=N)
+            bw_Xs[t], bw_W[t], bw_Xanc[t], sels[t], ancs[t] = x, W, x_anc, sel, anc
+
+        # t = 0 (PSVOwR.py:155-187)
+        x_tp1 = bw_Xanc[1]
+        x, q_lp, _ = self.sample_from_2_dist(self.q1_inv, self.BSim_q2, x_tp1, enc[0], eps[0])
+        f_lp = self.f.log_prob(x, x_tp1)
+        g_lp = self.g.log_prob(x, obs[:, 0])
+        mu_0 = self.preprocessed_X0
+        if not (self.use_bootstrap and self.use_2_q):
+            f_init = self.f.log_prob(mu_0, x)
+        else:
+            f_init = self.q0.log_prob(mu_0, x)
+        omega = f_init + f_lp + g_lp - q_lp
+        omega = omega - logsumexp(omega, 0)
+        W = f_init + g_lp
+        ut, it = pick(0)
+        (x, omega, W, q_lp), sel = self.resample_X([x, omega, W, q_lp], omega, u=ut, idx=it, sample_size=())
+        W = W - (q_lp + omega + logM)
+        ur, ir = pick_r(0)
+        x_anc, anc = self.resample_X(x, omega, u=ur, idx=ir, sample_size=N)
+        bw_Xs[0], bw_W[0], bw_Xanc[0], sels[0], ancs[0] = x, W, x_anc, sel, anc
+
+        self.idx_b, self.idx_r = torch.stack(sels), torch.stack(ancs)
+        return torch.stack(bw_Xs), torch.stack(bw_Xanc), torch.stack(bw_W)
+
+    def get_log_ZSMC(self, obs, noise):                   # PSVOwR.py:21-50
+        X_prevs, X_ancestors, log_Ws = self.SMC(obs, noise)
+        bw_Xs, bw_Xanc, bw_W = self.backward_simulation_w_proposal(X_prevs, log_Ws, obs, noise)
+        log_ZSMC = self.compute_log_ZSMC_wr(bw_W)
+        log = {"Xs": bw_Xanc.permute(2, 0, 1, 3), "X_prevs": X_prevs, "X_ancestors": X_ancestors,
+               "log_Ws": log_Ws, "idx_f": self.idx_f, "bw_Xs": bw_Xs, "bw_X_ancestors": bw_Xanc,
+               "bw_log_W": bw_W, "idx_b": self.idx_b, "idx_r": self.idx_r}
+        return log_ZSMC, log
+
+
+OBJECTIVES["PSVOwR"] = OraclePSVOwR

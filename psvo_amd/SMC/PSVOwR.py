@@ -1,0 +1,71 @@
+"""PSVOwR -- mirror of reference src/SMC/PSVOwR.py:8-198: PSVO whose backward simulation resamples
+ACROSS the chains after every step and accumulates a per-step ELBO.  The whole loop
+(PSVOwR.py:65-198) is ONE persistent HIP kernel with one workgroup per sequence
+(psvo_bsimwr_forward, psvo_amd/csrc/psvowr_fwd.hip); its reverse pass is psvo_bsimwr_backward."""
+import math
+
+import torch
+
+from .. import autograd
+from ..autograd import BsimWRFunction, Overlap, side_stream
+from .PSVO import PSVO
+
+
+class PSVOwR(PSVO):
+    def __init__(self, model, FLAGS, name="log_ZSMC"):
+        PSVO.__init__(self, model, FLAGS, name=name)
+
+    def get_log_ZSMC(self, obs, hidden, noise=None):
+        """PSVOwR.py:38-62.  Extra `noise` keys on top of PSVO's: u_r (T,B,N) uniforms of the cross-chain
+        draw or anc_r (T,B,N) int32 teacher-forced ancestors."""
+        batch_size, time, _ = obs.shape
+        self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
+
+        log = {}
+        self._ov = Overlap(side_stream(obs.device)) if (autograd.OVERLAP and obs.is_cuda) else None
+        self._sigmas = self.model.sigmas()
+        filt = self.SMC(hidden, obs, noise=noise)
+        bs = self.backward_simulation_w_resampling(filt, obs, noise=noise)
+        self._ov = None
+        # PSVOwR.py:144-148, 184-185: log_ZSMC = sum_t [logsumexp_n bw_log_W_t - log N], averaged over the batch
+        log_ZSMC = (bs["lseW"].sum(0) - time * math.log(float(self.n_particles))).mean()
+        log["Xs"] = bs["bwXanc"].permute(1, 0, 3, 2)                   # (B, T, N, Dx), PSVOwR.py:198
+        log["filter"], log["bsim"] = filt, bs
+        return log_ZSMC, log
+
+    def backward_simulation_w_resampling(self, filt, obs, noise=None):
+        model = self.model
+        Dx, T, N, B = self.Dx, self.time, self.n_particles, self.batch_size
+        M = self.n_particles_for_BSim_proposal
+        dev = obs.device
+        noise = noise or {}
+
+        _, preprocessed_obs = self.BS_preprocess_obs(obs)
+        bmu2 = self.BSim_q2.mean(preprocessed_obs).transpose(0, 1).contiguous()
+        minit = self.BSim_q_init.mean(preprocessed_obs[:, -1])
+        mu_0 = self.preprocessed_X0
+        if not (model.use_bootstrap and model.use_2_q):
+            imean, isig = self.f.mean(mu_0), self._sigma(self.f)                 # PSVOwR.py:167
+        else:
+            imean, isig = self._m0, self._sig0                                   # PSVOwR.py:169
+
+        eps_b = noise.get("eps_b")
+        if eps_b is None:
+            eps_b = self._randn(T, B, Dx, N, M, device=dev)
+        u_b, sel_in = noise.get("u_b"), noise.get("sel_b")
+        if u_b is None and sel_in is None:
+            u_b = self._rand(T, B, N, device=dev)
+        u_r, anc_in = noise.get("u_r"), noise.get("anc_r")
+        if u_r is None and anc_in is None:
+            u_r = self._rand(T, B, N, device=dev)
+        obs_TB = obs.transpose(0, 1).contiguous().float()
+
+        desc = self._desc(M)
+        gb = (self._gbuf(model.f_tran), self._gbuf(model.g_tran), self._gbuf(model.q1_inv_tran))
+        desc._gbufs = gb if all(v is not None for v in gb) else None
+        lseW, bwXanc, bwX, bwW, sel, anc = BsimWRFunction.apply(
+            desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, filt["Fm"], filt["logW"], filt["lse"],
+            *model.f_tran.hip_params(), *model.g_tran.hip_params(), *model.q1_inv_tran.hip_params(),
+            self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
+            bmu2, minit, self._sigma(self.BSim_q_init), imean, isig)
+        return {"lseW": lseW, "bwXanc": bwXanc, "bwX": bwX, "bwW": bwW, "sel": sel, "anc": anc}

@@ -175,6 +175,60 @@ class BsimFunction(torch.autograd.Function):
             r["dminit_part"].sum(1), r["dsig_init"], r["dimean_part"].sum(1), r["disig"])
 
 
+class BsimWRFunction(torch.autograd.Function):
+    """psvo_bsimwr_forward / psvo_bsimwr_backward (PSVOwR: cross-chain resampling, per-step ELBO).
+
+    apply(desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, Fm, logW, lse,
+          fW1, fb1, fW2, fb2, gW1, gb1, gW2, gb2, qW1, qb1, qW2, qb2,
+          sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig)
+      -> lseW (T,B) [differentiable]; bwXanc, bwX (T,B,Dx,N), bwW (T,B,N), sel, anc (T,B,N) [constants]
+    """
+
+    @staticmethod
+    def forward(ctx, desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, Fm, logW, lse, *t):
+        t = [_cf(v) for v in t]
+        f, g, q = tuple(t[0:4]), tuple(t[4:8]), tuple(t[8:12])
+        sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig = t[12:21]
+        filt = {"Fm": _cf(Fm), "logW": _cf(logW), "lse": _cf(lse)}
+        ov = getattr(desc, "_ov", None)
+        if ov is not None and ov.filter_done is not None:
+            torch.cuda.current_stream().wait_event(ov.filter_done)
+        ctx.gbufs = getattr(desc, "_gbufs", None)
+        need = any(ctx.needs_input_grad)
+        bs = ops.bsimwr_forward(desc, filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean,
+                                isig, obs_TB, eps_b, u_b=u_b, u_r=u_r, sel_in=sel_in, anc_in=anc_in, save=need)
+        ctx.desc, ctx.filt, ctx.bs = desc, filt, bs
+        ctx.saved = (f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b)
+        ctx.mark_non_differentiable(bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"])
+        return bs["lseW"], bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"]
+
+    @staticmethod
+    def backward(ctx, dlseW, *_):
+        desc = ctx.desc
+        f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b = ctx.saved
+        ov = getattr(desc, "_ov", None)
+
+        def after_kernel():
+            if ov is not None:
+                ov.bsim_grads_ready = torch.cuda.Event()
+                ov.bsim_grads_ready.record()
+        r = ops.bsimwr_backward(desc, ctx.filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
+                                imean, isig, obs_TB, eps_b, ctx.bs, _cg(dlseW), gbufs=ctx.gbufs,
+                                after_kernel=after_kernel)
+        if ov is not None:
+            ov.bsim_wgrad_done = torch.cuda.Event()
+            ov.bsim_wgrad_done.record()
+        Dx, Dy, H = desc.Dx, desc.Dy, desc.H
+        gb = ctx.gbufs or (None, None, None)
+        none4 = (None,) * 4
+        gf = none4 if gb[0] is not None else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
+        gg = none4 if gb[1] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
+        gq = none4 if gb[2] is not None else ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
+        return (None,) * 7 + (r["dFm"], r["dlogW"], r["dlse"]) + tuple(gf) + tuple(gg) + tuple(gq) + (
+            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2"], r["dminit"], r["dsig_init"],
+            r["dimean"], r["disig"])
+
+
 class BiLSTMFunction(torch.autograd.Function):
     """psvo_bilstm_forward / psvo_bilstm_backward: one bidirectional LSTMBlockCell layer."""
 

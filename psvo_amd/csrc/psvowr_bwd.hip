@@ -1,0 +1,594 @@
+// Reverse mode of psvo_bsimwr_forward (PSVOwR, reference src/SMC/PSVOwR.py:65-198 under TensorFlow autodiff).
+// One persistent workgroup (512 lanes) per sequence walks t = 0 .. T-1 over the N*M (chain, sub-particle)
+// items in rounds.  With a = d loss / d bw_log_W[t, chain], pi_m = exp(omega_m), sel the drawn sub-particle and
+//     bw_log_W = logsumexp_m(omega_raw) - phi_sel - log M,    omega_raw = Lambda + phi + g - q
+// the coefficients are
+//     d Lambda_m (d iota_m at t = 0) = d g_m = a pi_m,   d phi_m = a (pi_m - delta_{m,sel}),   d q_m = -a pi_m.
+// Unlike PSVO, sum_m d Lambda_m = a != 0, so the normalisation of the forward weights does receive gradient:
+// d lse[t-1] = - sum_j d W^_j is written for psvo_filter_backward.
+// The cross-chain resampling (bwXanc_t[k] = bwX_t[anc_t[k]]) back-propagates as a scatter-add of
+// d bwXanc_t into the selected sub-particle of the parent chain (LDS float atomics, N*Dx per step).
+// The forward tile is recomputed (second pass) exactly as in bsim_bwd_impl.h: per-j partial sums are
+// reduce-scattered over the 16 quads of a wave with a butterfly and folded over waves through LDS.
+#include "common.h"
+
+namespace psvo {
+
+struct WrBwdArgs {
+    int B, T, N;
+    psvo_mlp f, g, q1inv;
+    const float *Fm, *logW, *lse;
+    const float *sig_f, *sig_g, *sig_q1inv, *sig_bq2;
+    const float *bmu2, *minit, *sig_init, *imean, *isig;
+    const float *obs, *eps_b;
+    const float *bwXanc, *bwW, *lseW;
+    const int32_t *sel, *anc;
+    const float *lam2_all, *om_all, *mu1_all;
+    const float* dlseW;  // (T,B)
+    float *xt, *dFt, *dGt, *dmu1;
+    float *dFm, *dlogW, *dlse, *dbmu2, *dminit, *dimean, *sacc;
+};
+
+template <int DX, int DY>
+struct WAcc {   // same slots as BAcc in bsim_bwd_impl.h (shares bsim_bwd_finalize's algebra)
+    static constexpr int kSc = 0, kSmm1 = DX, kSmb = 2 * DX, kSmm = 3 * DX, kSf = 4 * DX, kSinit = 5 * DX,
+                         kSiota = 6 * DX, kSg = 7 * DX, kN = 7 * DX + DY;
+};
+
+template <int DX>
+struct WbSlot {
+    static constexpr int kFloats = (DX <= 3) ? 4 : 8;
+};
+
+template <int DX>
+__device__ __forceinline__ void wb_read_slot(const float* p, float (&F)[DX], float& W) {
+    const float4 e = *reinterpret_cast<const float4*>(p);
+    if constexpr (DX <= 3) {
+        F[0] = e.x;
+        if constexpr (DX > 1) F[1] = e.y;
+        if constexpr (DX > 2) F[2] = e.z;
+        W = e.w;
+    } else {
+        F[0] = e.x; F[1] = e.y; F[2] = e.z; F[3] = e.w;
+        W = p[4];
+    }
+}
+
+template <int CH, int NA, int NN, int MASK>
+__device__ __forceinline__ void wb_rs_stage(float (&A)[CH][NA], int bit) {
+#pragma unroll
+    for (int i = 0; i < NN / 2; ++i) {
+#pragma unroll
+        for (int d = 0; d < NA; ++d) {
+            const float lo = A[i][d], hi = A[i + NN / 2][d];
+            const float send = bit ? lo : hi;
+            const float keep = bit ? hi : lo;
+            A[i][d] = keep + xor_lane<MASK>(send);
+        }
+    }
+}
+
+template <int DX, int DY, int H, int M>
+__global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    using AC = WAcc<DX, DY>;
+    constexpr int PS = WbSlot<DX>::kFloats;
+    constexpr bool kRolled = true;
+    constexpr int NA = DX + 1;
+    // forward-tile entries per butterfly: 16 (one owned entry per lane after four reduce-scatter stages over the 16
+    // quads of a wave), or 8 for Dx >= 3 (three stages, then the two half-waves are summed) to stay inside 256 VGPRs
+    constexpr int CH = (DX <= 2) ? 16 : 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NTB = blockDim.x, nw = NTB >> 6;
+    const int B = a.B, T = a.T, N = a.N;
+    const int NP = (N + 3) & ~3;
+    const int b = blockIdx.x;
+    const int cpr = NTB / M;
+    const int rounds = (N + cpr - 1) / cpr;
+    const int cl = tid / M, m = tid % M, q = m & 3;
+
+    float* wf = smem;
+    float* wg = wf + MQ::kSize;
+    float* wqi = wg + MG::kSize;
+    float* tile = wqi + MQ::kSize;              // [2][NP][PS]
+    float* jacc = tile + 2 * NP * PS;           // [nw][NA][NP] wave-private d F' / d W^ sums of the step
+    float* dxa = jacc + nw * NA * NP;           // [DX][N] d loss / d bwXanc_t (input of the step)
+    float* dxs = dxa + DX * N;                  // [DX][N] ... scattered to the parent chains' selected sub-particle
+    float* dxn = dxs + DX * N;                  // [DX][N] d loss / d bwXanc_{t+1} (output of the step)
+    float* cacc = dxn + DX * N;                 // [3][DX][N] per-chain d bmu2 / d minit / d imean contributions
+    float* red = cacc + 3 * DX * N;             // 64
+
+    MQ::load(wf, a.f, tid, NTB);
+    MG::load(wg, a.g, tid, NTB);
+    MQ::load(wqi, a.q1inv, tid, NTB);
+    for (int i = tid; i < DX * N; i += NTB) dxa[i] = 0.f;
+
+    const float kappa = sqrtf(0.5f * kLog2e);
+    float isf[DX], rp[DX], isg[DY];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        isf[d] = 1.f / a.sig_f[d];
+        rp[d] = isf[d] * kappa;
+    }
+#pragma unroll
+    for (int e = 0; e < DY; ++e) isg[e] = 1.f / a.sig_g[e];
+    float pc[DX], pic[DX], pi1[DX], pi2[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        pi1[d] = 1.f / a.sig_q1inv[d];
+        pi2[d] = 1.f / a.sig_bq2[d];
+        pic[d] = pi1[d] + pi2[d];
+        pc[d] = 1.f / pic[d];
+    }
+    float s_init[DX], i_isig[DX], im[DX], mi[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        s_init[d] = a.sig_init[d];
+        i_isig[d] = 1.f / a.isig[d];
+        im[d] = a.imean[b * DX + d];
+        mi[d] = a.minit[b * DX + d];
+    }
+    const float ninf = -__builtin_huge_valf();
+
+    auto stage = [&](int tt, float* buf) {
+        const size_t tb = (size_t)tt * B + b;
+        const float l = a.lse[tb];
+        for (int j = tid; j < NP; j += NTB) {
+            const int jc = j < N ? j : N - 1;
+            float v[DX + 1];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) v[d] = a.Fm[(tb * DX + d) * N + jc] * rp[d];
+            v[DX] = j < N ? (a.logW[tb * N + jc] - l) * kLog2e : ninf;
+            if constexpr (DX <= 3) {
+                float4 o;
+                o.x = v[0];
+                o.y = DX > 1 ? v[DX > 1 ? 1 : 0] : 0.f;
+                o.z = DX > 2 ? v[DX > 2 ? 2 : 0] : 0.f;
+                o.w = v[DX];
+                *reinterpret_cast<float4*>(buf + j * PS) = o;
+            } else {
+                *reinterpret_cast<float4*>(buf + j * PS) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(v[4], 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    if (T >= 2) stage(0, tile);   // step t reads forward tile t-1
+
+    float acc[AC::kN];
+#pragma unroll
+    for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
+    const int nq = NP >> 2;
+    constexpr int b0 = 2, b1 = 3, b2 = 4, b3 = 5;   // quad-index bits of the lane id
+    const int ebase = ((lane >> b0) & 1) * (CH / 2) + ((lane >> b1) & 1) * (CH / 4) + ((lane >> b2) & 1) * (CH / 8) +
+                      (CH >= 16 ? ((lane >> b3) & 1) * (CH / 16) : 0);
+    const bool owner = CH >= 16 || ((lane >> b3) & 1) == 0;
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const size_t tb = (size_t)t * B + b;
+        const bool last = (t == T - 1), first = (t == 0);
+        const float* cur = tile + ((t + 1) & 1) * NP * PS;   // tile(t-1)
+        float* nxt = tile + (t & 1) * NP * PS;               // tile(t), read at step t+1
+        if (t + 1 < T && t >= 1) stage(t, nxt);
+
+        // ---- phase 0: scatter d bwXanc_t to the parent chains (bwXanc_t[k] = bwX_t[anc_t[k]]) -----------------
+        for (int i = tid; i < DX * N; i += NTB) dxs[i] = 0.f;
+        for (int i = tid; i < nw * NA * NP; i += NTB) jacc[i] = 0.f;
+        __syncthreads();
+        if (tid < N) {
+            const int p = a.anc[tb * N + tid];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) atomicAdd(&dxs[d * N + p], dxa[d * N + tid]);
+        }
+        __syncthreads();
+
+        float bm[DX], y[DY];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) bm[d] = a.bmu2[tb * DX + d];
+#pragma unroll
+        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+        const float lw = a.lseW[tb], dlw = a.dlseW[tb];
+        float* ja = jacc + wave * NA * NP;
+
+        // ---- phase 1: the (chain, sub-particle) items ----------------------------------------------------------
+        for (int r = 0; r < rounds; ++r) {
+            const int n_raw = r * cpr + cl;
+            const bool valid = n_raw < N;
+            const int n = valid ? n_raw : N - 1;
+            const float aw = valid ? dlw * expf(a.bwW[tb * N + n] - lw) : 0.f;   // d loss / d bw_log_W[t, n]
+            const int sel = a.sel[tb * N + n];
+            float xp[DX], eps[DX], mu1[DX], mu[DX], x[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                eps[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
+                if (!last) {
+                    xp[d] = a.bwXanc[((tb + B) * DX + d) * N + n];
+                    mu1[d] = a.mu1_all[(tb * DX + d) * N + n];
+                    mu[d] = pc[d] * fmaf(pi1[d], mu1[d], pi2[d] * bm[d]);
+                    x[d] = fmaf(pc[d], eps[d], mu[d]);
+                } else {
+                    xp[d] = 0.f;
+                    mu1[d] = 0.f;
+                    mu[d] = mi[d];
+                    x[d] = fmaf(s_init[d], eps[d], mu[d]);
+                }
+            }
+            const float pi_m = valid ? expf(a.om_all[(tb * N + n) * M + m]) : 0.f;
+            const float issel = (m == sel) ? 1.f : 0.f;
+            const float cg = aw * pi_m;                 // d g_m = d Lambda_m = d iota_m
+            const float cphi = aw * (pi_m - issel);     // d phi_m
+
+            float dxt[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) dxt[d] = issel * dxs[d * N + n];
+
+            if (!first) {
+                const float lam2 = a.lam2_all[(tb * N + n) * M + m];
+                float xq[4][DX], lq[4], dl[4], U[4][DX], V[4][DX];
+                quad_bcast4(lam2, lq);
+                quad_bcast4(cg, dl);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    float t4[4];
+                    quad_bcast4(x[d] * rp[d], t4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xq[i][d] = t4[i];
+                        U[i][d] = 0.f;
+                        V[i][d] = 0.f;
+                    }
+                }
+                for (int c0 = 0; c0 < nq; c0 += CH) {
+                    float A[CH][NA];
+#pragma unroll
+                    for (int i2 = 0; i2 < CH; ++i2) {
+                        const int e = c0 + i2;
+#pragma unroll
+                        for (int d = 0; d < NA; ++d) A[i2][d] = 0.f;
+                        if (e < nq) {
+                            float F[DX], W;
+                            wb_read_slot<DX>(cur + (e * 4 + q) * PS, F, W);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                float u[DX], l = W;
+#pragma unroll
+                                for (int d = 0; d < DX; ++d) {
+                                    u[d] = xq[i][d] - F[d];
+                                    l = fmaf(-u[d], u[d], l);
+                                }
+                                const float p = exp2_fast(l - lq[i]);
+                                const float c = dl[i] * p;
+                                A[i2][DX] += c;
+#pragma unroll
+                                for (int d = 0; d < DX; ++d) {
+                                    const float pu = p * u[d];
+                                    U[i][d] += pu;
+                                    V[i][d] = fmaf(pu, u[d], V[i][d]);
+                                    A[i2][d] = fmaf(c, u[d], A[i2][d]);
+                                }
+                            }
+                        }
+                    }
+                    wb_rs_stage<CH, NA, CH, (1 << b0)>(A, (lane >> b0) & 1);
+                    wb_rs_stage<CH, NA, CH / 2, (1 << b1)>(A, (lane >> b1) & 1);
+                    wb_rs_stage<CH, NA, CH / 4, (1 << b2)>(A, (lane >> b2) & 1);
+                    if constexpr (CH >= 16) {
+                        wb_rs_stage<CH, NA, CH / 8, (1 << b3)>(A, (lane >> b3) & 1);
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < NA; ++d) A[0][d] += xor_lane<(1 << b3)>(A[0][d]);
+                    }
+                    const int e = c0 + ebase;       // the one entry this lane owns; the wave's rounds accumulate
+                    if (owner && e < nq) {
+#pragma unroll
+                        for (int d = 0; d < NA; ++d) ja[d * NP + e * 4 + q] += A[0][d];
+                    }
+                }
+                float Uo[DX], Vo[DX];
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    Uo[d] = 0.f;
+                    Vo[d] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) {
+                        const float u = group_sum<4>(U[i][d]), v = group_sum<4>(V[i][d]);
+                        if (i == q) {
+                            Uo[d] = u;
+                            Vo[d] = v;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    dxt[d] -= cg * Uo[d] * isf[d] / kappa;
+                    acc[AC::kSf + d] += cg * (Vo[d] / (kappa * kappa) - 1.f) * isf[d];
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    const float z = (x[d] - im[d]) * i_isig[d];
+                    dxt[d] -= cg * z * i_isig[d];
+                    acc[AC::kSiota + d] += cg * (z * z - 1.f) * i_isig[d];
+                }
+            }
+
+            float dxp_part[DX], dFo[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                dxp_part[d] = 0.f;
+                dFo[d] = 0.f;
+            }
+            if (!last) {
+                float fmx[DX];
+                MQ::template eval<kRolled>(wf, x, fmx);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    const float z = (xp[d] - fmx[d]) * isf[d];
+                    dFo[d] = cphi * z * isf[d];
+                    dxp_part[d] = -dFo[d];
+                    acc[AC::kSf + d] += cphi * (z * z - 1.f) * isf[d];
+                }
+                MQ::template bwd_input<kRolled>(wf, x, dFo, dxt);
+            }
+            if (valid) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    a.dFt[((tb * DX + d) * N + n) * M + m] = dFo[d];
+                    a.xt[((tb * DX + d) * N + n) * M + m] = x[d];
+                }
+            }
+            {
+                float gm[DY], dGo[DY];
+                MG::template eval<kRolled>(wg, x, gm);
+#pragma unroll
+                for (int k = 0; k < DY; ++k) {
+                    const float z = (y[k] - gm[k]) * isg[k];
+                    dGo[k] = cg * z * isg[k];
+                    acc[AC::kSg + k] += cg * (z * z - 1.f) * isg[k];
+                    if (valid) a.dGt[((tb * DY + k) * N + n) * M + m] = dGo[k];
+                }
+                MG::template bwd_input<kRolled>(wg, x, dGo, dxt);
+            }
+
+            // ---- reduce over the chain's M sub-particles --------------------------------------------------------
+            float dmu[DX], sce[DX], dxp[DX], dim[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                dmu[d] = group_sum<M>(dxt[d]);
+                sce[d] = group_sum<M>(dxt[d] * eps[d]);
+                dxp[d] = group_sum<M>(dxp_part[d]);
+                dim[d] = first ? group_sum<M>(cg * (x[d] - im[d]) * i_isig[d] * i_isig[d]) : 0.f;
+            }
+            const bool lead = (m == 0) && valid;
+            float outv[DX];
+            if (!last) {
+                float dmu1[DX];
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    dmu1[d] = dmu[d] * pc[d] * pi1[d];
+                    outv[d] = dmu[d] * pc[d] * pi2[d];
+                    if (lead) {
+                        a.dmu1[(tb * DX + d) * N + n] = dmu1[d];
+                        acc[AC::kSc + d] += sce[d] + aw * pic[d];
+                        acc[AC::kSmm1 + d] += dmu[d] * mu1[d];
+                        acc[AC::kSmb + d] += dmu[d] * bm[d];
+                        acc[AC::kSmm + d] += dmu[d] * mu[d];
+                    }
+                }
+                MQ::template bwd_input<kRolled>(wqi, xp, dmu1, dxp);
+            } else {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    outv[d] = dmu[d];
+                    if (lead) {
+                        a.dmu1[(tb * DX + d) * N + n] = 0.f;
+                        acc[AC::kSinit + d] += sce[d] + aw / s_init[d];
+                    }
+                }
+            }
+            if (lead) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    dxn[d * N + n] = dxp[d];
+                    cacc[(0 * DX + d) * N + n] = outv[d];
+                    cacc[(1 * DX + d) * N + n] = dim[d];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: per-sequence outputs of the step ----------------------------------------------------------------
+        for (int i = tid; i < DX * N; i += NTB) dxa[i] = dxn[i];     // becomes d bwXanc_{t+1}
+        if (wave < 2 * DX) {   // wave w sums vector w of cacc over the chains
+            float s = 0.f;
+            for (int i = lane; i < N; i += 64) s += cacc[wave * N + i];
+            s = wave_sum(s);
+            if (lane == 0) {
+                const int which = wave / DX, d = wave % DX;
+                if (which == 0) {
+                    a.dbmu2[tb * DX + d] = last ? 0.f : s;
+                    if (last) a.dminit[(size_t)b * DX + d] = s;
+                } else if (first) {
+                    a.dimean[(size_t)b * DX + d] = s;
+                }
+            }
+        }
+        if (!first) {
+            const size_t tbm = tb - B;
+            float wsum = 0.f;
+            for (int i = tid; i < NA * N; i += NTB) {
+                const int d = i / N, j = i - d * N;
+                float s = 0.f;
+                for (int w = 0; w < nw; ++w) s += jacc[(w * NA + d) * NP + j];
+                if (d < DX) a.dFm[(tbm * DX + d) * N + j] = s * isf[d] / kappa;
+                else {
+                    a.dlogW[tbm * N + j] = s;
+                    wsum += s;
+                }
+            }
+            // d lse[t-1] = - sum_j d W^_j
+            wsum = wave_sum(wsum);
+            if (lane == 0) red[wave] = wsum;
+            __syncthreads();
+            if (tid == 0) {
+                float s = 0.f;
+                for (int w = 0; w < nw; ++w) s += red[w];
+                a.dlse[tbm] = -s;
+            }
+        }
+        if (last) {
+            for (int i = tid; i < NA * N; i += NTB) {
+                const int d = i / N, j = i - d * N;
+                if (d < DX) a.dFm[(tb * DX + d) * N + j] = 0.f;
+                else a.dlogW[tb * N + j] = 0.f;
+            }
+            if (tid == 0) a.dlse[tb] = 0.f;
+        }
+        __syncthreads();
+    }
+
+    for (int i = 0; i < AC::kN; ++i) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < AC::kN; ++k) v = (k == i) ? acc[k] : v;
+        v = wave_sum(v);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += red[w];
+            a.sacc[(size_t)b * AC::kN + i] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// same algebra as bsim_bwd_finalize (one row of sums per sequence)
+template <int DX, int DY>
+__global__ void psvowr_bwd_finalize(const float* __restrict__ sacc, int rows, const float* sig_q1inv, const float* sig_bq2,
+                                    float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
+                                    float* disig) {
+    using AC = WAcc<DX, DY>;
+    __shared__ float tot[AC::kN];
+    const int d = threadIdx.x;
+    for (int k = 0; k < AC::kN; ++k) {
+        float v = 0.f;
+        for (int r = d; r < rows; r += 64) v += sacc[(size_t)r * AC::kN + k];
+        v = wave_sum(v);
+        if (d == 0) tot[k] = v;
+    }
+    __syncthreads();
+    if (d < DX) {
+        const float i1 = 1.f / sig_q1inv[d], i2 = 1.f / sig_bq2[d];
+        const float c = 1.f / (i1 + i2);
+        const float dc = tot[AC::kSc + d] + tot[AC::kSmm + d] / c;
+        const float di1 = c * tot[AC::kSmm1 + d] - c * c * dc;
+        const float di2 = c * tot[AC::kSmb + d] - c * c * dc;
+        dsig_q1inv[d] = -i1 * i1 * di1;
+        dsig_bq2[d] = -i2 * i2 * di2;
+        dsig_f[d] = tot[AC::kSf + d];
+        dsig_init[d] = tot[AC::kSinit + d];
+        disig[d] = tot[AC::kSiota + d];
+    }
+    if (d < DY) dsig_g[d] = tot[AC::kSg + d];
+}
+
+struct WrBwdOut {
+    float *dsig_f, *dsig_g, *dsig_q1inv, *dsig_bq2, *dsig_init, *disig;
+};
+
+template <int DX, int DY, int H, int M>
+static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stream) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    constexpr int PS = WbSlot<DX>::kFloats;
+    const int NP = (a.N + 3) & ~3;
+    long long items = (long long)a.N * M;
+    int NTB = (int)(((items + 63) / 64) * 64);
+    if (NTB > 512) NTB = 512;
+    if (a.N > NTB || 2 * DX > NTB / 64) return PSVO_ERR_UNSUPPORTED;
+    const int nw = NTB / 64;
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nw * (DX + 1) * NP +
+                                        6 * DX * (size_t)a.N + 64);
+    if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
+    clear_hip_error();
+    hipLaunchKernelGGL((psvowr_bwd_kernel<DX, DY, H, M>), dim3(a.B), dim3(NTB), lds, stream, a);
+    hipLaunchKernelGGL((psvowr_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc, a.B, a.sig_q1inv, a.sig_bq2,
+                       o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
+    return launch_status();
+}
+
+template <int DX, int DY, int H>
+static int wb_dispatch_m(const WrBwdArgs& a, const WrBwdOut& o, int M, hipStream_t s) {
+    switch (M) {
+        case 4: return launch_wr_bwd<DX, DY, H, 4>(a, o, s);
+        case 8: return launch_wr_bwd<DX, DY, H, 8>(a, o, s);
+        case 16: return launch_wr_bwd<DX, DY, H, 16>(a, o, s);
+        case 32: return launch_wr_bwd<DX, DY, H, 32>(a, o, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+template <int DX, int DY>
+static int wb_dispatch_h(const WrBwdArgs& a, const WrBwdOut& o, int H, int M, hipStream_t s) {
+    switch (H) {
+        case 16: return wb_dispatch_m<DX, DY, 16>(a, o, M, s);
+        case 32: return wb_dispatch_m<DX, DY, 32>(a, o, M, s);
+        case 64: return wb_dispatch_m<DX, DY, 64>(a, o, M, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+template <int DX>
+static int wb_dispatch_dy(const WrBwdArgs& a, const WrBwdOut& o, int Dy, int H, int M, hipStream_t s) {
+    switch (Dy) {
+        case 1: return wb_dispatch_h<DX, 1>(a, o, H, M, s);
+        case 2: return wb_dispatch_h<DX, 2>(a, o, H, M, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace psvo
+
+extern "C" int psvo_bsimwr_backward(
+    const psvo_desc* desc, const float* Fm, const float* logW, const float* lse, const psvo_mlp* f, const psvo_mlp* g,
+    const psvo_mlp* q1_inv, const float* sig_f, const float* sig_g, const float* sig_q1inv, const float* sig_bq2,
+    const float* bmu2, const float* minit, const float* sig_init, const float* imean, const float* isig,
+    const float* obs, const float* eps_b, const float* bwXanc, const float* bwW, const float* lseW, const int32_t* sel,
+    const int32_t* anc, const float* lam2_all, const float* om_all, const float* mu1_all, const float* dlseW, float* xt,
+    float* dFt, float* dGt, float* dmu1, float* dFm, float* dlogW, float* dlse, float* dbmu2, float* dminit,
+    float* dimean, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init, float* disig,
+    float* sacc, void* stream) {
+    using namespace psvo;
+    if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 || !bmu2 ||
+        !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwXanc || !bwW || !lseW || !sel || !anc ||
+        !lam2_all || !om_all || !mu1_all || !dlseW || !xt || !dFt || !dGt || !dmu1 || !dFm || !dlogW || !dlse ||
+        !dbmu2 || !dminit || !dimean || !dsig_f || !dsig_g || !dsig_q1inv || !dsig_bq2 || !dsig_init || !disig || !sacc)
+        return PSVO_ERR_INVALID;
+    if (desc->B <= 0 || desc->T < 2 || desc->N <= 0 || desc->M <= 0) return PSVO_ERR_INVALID;
+    if (desc->N > 512 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
+    WrBwdArgs a;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N;
+    a.f = *f; a.g = *g; a.q1inv = *q1_inv;
+    a.Fm = Fm; a.logW = logW; a.lse = lse;
+    a.sig_f = sig_f; a.sig_g = sig_g; a.sig_q1inv = sig_q1inv; a.sig_bq2 = sig_bq2;
+    a.bmu2 = bmu2; a.minit = minit; a.sig_init = sig_init; a.imean = imean; a.isig = isig;
+    a.obs = obs; a.eps_b = eps_b; a.bwXanc = bwXanc; a.bwW = bwW; a.lseW = lseW; a.sel = sel; a.anc = anc;
+    a.lam2_all = lam2_all; a.om_all = om_all; a.mu1_all = mu1_all; a.dlseW = dlseW;
+    a.xt = xt; a.dFt = dFt; a.dGt = dGt; a.dmu1 = dmu1; a.dFm = dFm; a.dlogW = dlogW; a.dlse = dlse;
+    a.dbmu2 = dbmu2; a.dminit = dminit; a.dimean = dimean; a.sacc = sacc;
+    WrBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (desc->Dx) {
+        case 2: return wb_dispatch_dy<2>(a, o, desc->Dy, desc->H, desc->M, s);
+        case 3: return wb_dispatch_dy<3>(a, o, desc->Dy, desc->H, desc->M, s);
+        case 4: return wb_dispatch_dy<4>(a, o, desc->Dy, desc->H, desc->M, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}

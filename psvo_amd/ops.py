@@ -342,6 +342,88 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
     return out
 
 
+def bsimwr_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
+                   imean, isig, obs, eps_b, u_b=None, u_r=None, sel_in=None, anc_in=None, save=False):
+    """psvo_bsimwr_forward (PSVOwR).  Returns dict(bwX, bwXanc, bwW, lseW, sel, anc[, lam2, om, mu1])."""
+    lib = _lib.load()
+    B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
+    dev = eps_b.device
+    fs = _mlp_struct(f, Dx, H, Dx, "f")
+    gs = _mlp_struct(g, Dx, H, Dy, "g")
+    qs = _mlp_struct(q1_inv, Dx, H, Dx, "q1_inv")
+    _chk(filt["Fm"], (T, B, Dx, N), "Fm")
+    _chk(filt["logW"], (T, B, N), "logW"); _chk(filt["lse"], (T, B), "lse")
+    _chk(sig_f, (Dx,), "sig_f"); _chk(sig_g, (Dy,), "sig_g")
+    _chk(sig_q1inv, (Dx,), "sig_q1inv"); _chk(sig_bq2, (Dx,), "sig_bq2")
+    _chk(bmu2, (T, B, Dx), "bmu2"); _chk(minit, (B, Dx), "minit"); _chk(sig_init, (Dx,), "sig_init")
+    _chk(imean, (B, Dx), "imean"); _chk(isig, (Dx,), "isig")
+    _chk(obs, (T, B, Dy), "obs"); _chk(eps_b, (T, B, Dx, N, M), "eps_b")
+    _chk(u_b, (T, B, N), "u_b"); _chk(sel_in, (T, B, N), "sel_in", torch.int32)
+    _chk(u_r, (T, B, N), "u_r"); _chk(anc_in, (T, B, N), "anc_in", torch.int32)
+    if (u_b is None and sel_in is None) or (u_r is None and anc_in is None):
+        raise ValueError("PSVOwR needs uniforms (`u_b`, `u_r`) or teacher-forced indices (`sel_in`, `anc_in`)")
+    z = lambda *s: torch.empty(*s, device=dev)
+    zi = lambda *s: torch.empty(*s, device=dev, dtype=torch.int32)
+    out = {"bwX": z(T, B, Dx, N), "bwXanc": z(T, B, Dx, N), "bwW": z(T, B, N), "lseW": z(T, B),
+           "sel": zi(T, B, N), "anc": zi(T, B, N),
+           "lam2": z(T, B, N, M) if save else None, "om": z(T, B, N, M) if save else None,
+           "mu1": z(T, B, Dx, N) if save else None}
+    _mark("psvo_bsimwr_forward", 0)
+    st = lib.psvo_bsimwr_forward(
+        ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
+        ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs),
+        _ptr(sig_f), _ptr(sig_g), _ptr(sig_q1inv), _ptr(sig_bq2), _ptr(bmu2), _ptr(minit), _ptr(sig_init),
+        _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(u_b), _ptr(u_r), _ptr(sel_in), _ptr(anc_in),
+        _ptr(out["bwX"]), _ptr(out["bwXanc"]), _ptr(out["bwW"]), _ptr(out["lseW"]), _ptr(out["sel"]),
+        _ptr(out["anc"]), _ptr(out["lam2"]), _ptr(out["om"]), _ptr(out["mu1"]), _stream())
+    _mark("psvo_bsimwr_forward", 1)
+    _lib.check(st, "psvo_bsimwr_forward")
+    return out
+
+
+def bsimwr_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig,
+                    obs, eps_b, bs, dlseW, gbufs=None, after_kernel=None):
+    """psvo_bsimwr_backward + psvo_mlp_wgrad.  `bs` = bsimwr_forward(..., save=True) outputs."""
+    lib = _lib.load()
+    B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
+    dev = eps_b.device
+    fs = _mlp_struct(f, Dx, H, Dx, "f")
+    gs = _mlp_struct(g, Dx, H, Dy, "g")
+    qs = _mlp_struct(q1_inv, Dx, H, Dx, "q1_inv")
+    _chk(dlseW, (T, B), "dlseW")
+    for k, shp in (("lam2", (T, B, N, M)), ("om", (T, B, N, M)), ("mu1", (T, B, Dx, N)), ("bwXanc", (T, B, Dx, N)),
+                   ("bwW", (T, B, N)), ("lseW", (T, B))):
+        if bs.get(k) is None:
+            raise ValueError("bsimwr_backward needs bsimwr_forward(save=True) outputs (missing %s)" % k)
+        _chk(bs[k], shp, k)
+    z = lambda *s: torch.empty(*s, device=dev)
+    out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
+           "dFm": z(T, B, Dx, N), "dlogW": z(T, B, N), "dlse": z(T, B), "dbmu2": z(T, B, Dx),
+           "dminit": z(B, Dx), "dimean": z(B, Dx),
+           "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx)}
+    sacc = z(B, lib.psvo_bsim_acc_size(Dx, Dy))
+    _mark("psvo_bsimwr_backward", 0)
+    st = lib.psvo_bsimwr_backward(
+        ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
+        ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs),
+        _ptr(sig_f), _ptr(sig_g), _ptr(sig_q1inv), _ptr(sig_bq2), _ptr(bmu2), _ptr(minit), _ptr(sig_init),
+        _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(bs["bwXanc"]), _ptr(bs["bwW"]), _ptr(bs["lseW"]),
+        _ptr(bs["sel"]), _ptr(bs["anc"]), _ptr(bs["lam2"]), _ptr(bs["om"]), _ptr(bs["mu1"]), _ptr(dlseW),
+        _ptr(out["xt"]), _ptr(out["dFt"]), _ptr(out["dGt"]), _ptr(out["dmu1"]),
+        _ptr(out["dFm"]), _ptr(out["dlogW"]), _ptr(out["dlse"]), _ptr(out["dbmu2"]), _ptr(out["dminit"]),
+        _ptr(out["dimean"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
+        _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(sacc), _stream())
+    _mark("psvo_bsimwr_backward", 1)
+    _lib.check(st, "psvo_bsimwr_backward")
+    if after_kernel is not None:
+        after_kernel()
+    gb = gbufs or (None, None, None)
+    out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx, grad=gb[0])
+    out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy, grad=gb[1])
+    out["gq1inv"] = mlp_wgrad(bs["bwXanc"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx, grad=gb[2])
+    return out
+
+
 def reduce_rows(part, nrows, stride, n, out, accumulate=False):
     """psvo_reduce_rows: out[p] (+)= sum_r part[r*stride + p]; `part` may be a strided view (its data_ptr is used)."""
     lib = _lib.load()

@@ -12,6 +12,7 @@ from .rslts_saving.rslts_saving import NumpyEncoder, create_RLT_DIR, save_experi
 from .SMC.AESMC import AESMC
 from .SMC.IWAE import IWAE
 from .SMC.PSVO import PSVO
+from .SMC.PSVOwR import PSVOwR
 from .SMC.SVO import SVO
 from .trainer import trainer
 from .utils.data_generator import generate_dataset
@@ -55,12 +56,12 @@ def main(FLAGS):
     SSM_model = SSM(FLAGS).to(device)
 
     # at most one of them can be set to True (runner.py:67 -- PSVOwR is missing from the reference's assert)
-    assert FLAGS.PSVO + FLAGS.SVO + FLAGS.AESMC + FLAGS.IWAE < 2
+    assert FLAGS.PSVO + FLAGS.PSVOwR + FLAGS.SVO + FLAGS.AESMC + FLAGS.IWAE < 2
 
     if FLAGS.PSVO:
         SMC_train = PSVO(SSM_model, FLAGS)
     elif FLAGS.PSVOwR:
-        raise NotImplementedError("PSVOwR is the next objective on the list (SURVEY.md section 8f-3); not built yet")
+        SMC_train = PSVOwR(SSM_model, FLAGS)
     elif FLAGS.SVO:
         SMC_train = SVO(SSM_model, FLAGS)
     elif FLAGS.AESMC:

@@ -34,6 +34,10 @@ def noise_to_hip(noise, device):
         out["u_b"] = f32(noise["u_b"].permute(0, 2, 1))
     if noise.get("idx_b") is not None:
         out["sel_b"] = noise["idx_b"].permute(0, 2, 1).to(torch.int32).contiguous().to(device)
+    if "u_r" in noise:
+        out["u_r"] = f32(noise["u_r"].permute(0, 2, 1))
+    if noise.get("idx_r") is not None:
+        out["anc_r"] = noise["idx_r"].permute(0, 2, 1).to(torch.int32).contiguous().to(device)
     return out
 
 

@@ -33,6 +33,12 @@ CASES = [
     ("PSVO", 1, 5, 36, 32, 4, 2, 32, False, True),
     ("PSVO", 2, 5, 130, 16, 2, 1, 64, True, False),
     ("PSVO", 1, 5, 20, 4, 3, 1, 32, False, False),
+    ("PSVOwR", 2, 6, 8, 4, 2, 1, 16, True, True),
+    ("PSVOwR", 2, 7, 64, 16, 2, 1, 32, True, True),
+    ("PSVOwR", 2, 6, 50, 8, 3, 1, 32, True, True),
+    ("PSVOwR", 1, 5, 36, 32, 4, 2, 32, False, True),
+    ("PSVOwR", 2, 5, 130, 16, 2, 1, 64, True, False),
+    ("PSVOwR", 1, 5, 20, 4, 3, 1, 32, False, False),
 ]
 
 
@@ -42,7 +48,8 @@ def _setup(obj, B, T, N, M, Dx, Dy, H, bootstrap, two_q, seed=0):
     from psvo_amd.SMC.PSVO import PSVO
     from psvo_amd.SMC.AESMC import AESMC
     from psvo_amd.SMC.IWAE import IWAE
-    cls = {"SVO": SVO, "PSVO": PSVO, "AESMC": AESMC, "IWAE": IWAE}[obj]
+    from psvo_amd.SMC.PSVOwR import PSVOwR
+    cls = {"SVO": SVO, "PSVO": PSVO, "AESMC": AESMC, "IWAE": IWAE, "PSVOwR": PSVOwR}[obj]
     hs = str(H)
     FLAGS = Hh.make_flags(obj, Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, batch_size=B, time=T,
                           q0_layers=hs, q1_layers=hs, q2_layers=hs, f_layers=hs, g_layers=hs,
@@ -62,11 +69,14 @@ def test_teacher_forced_parity(built_lib, case):
     FLAGS, model, smc, obs, noise = _setup(*case)
     z_ref, ref = Hh.run_oracle(model, FLAGS, obj, obs, noise)
     teacher = {"idx_f": ref["idx_f"]} if ref["idx_f"] is not None else {}
-    if obj == "PSVO":
+    if obj in ("PSVO", "PSVOwR"):
         teacher["idx_b"] = ref["idx_b"]
+    if obj == "PSVOwR":
+        teacher["idx_r"] = ref["idx_r"]
     nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
     nz.pop("u_f", None) if "idx_f" in nz else None
     nz.pop("u_b", None) if "sel_b" in nz else None
+    nz.pop("u_r", None) if "anc_r" in nz else None
     with torch.no_grad():
         z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
     torch.cuda.synchronize()
@@ -81,6 +91,12 @@ def test_teacher_forced_parity(built_lib, case):
         assert torch.allclose(Hh.w_to_ref(bs["flp"]), ref["f_log_probs"], atol=5e-4, rtol=1e-5)
         assert torch.allclose(Hh.w_to_ref(bs["glp"]), ref["g_log_probs"], atol=5e-4, rtol=1e-5)
         assert torch.allclose(Hh.w_to_ref(bs["Omega"]), ref["bw_log_Omegas"], atol=5e-4, rtol=1e-5)
+    if obj == "PSVOwR":
+        bs = log["bsim"]
+        assert torch.allclose(Hh.part_to_ref(bs["bwX"]), ref["bw_Xs"], atol=2e-4, rtol=1e-5)
+        assert torch.allclose(Hh.part_to_ref(bs["bwXanc"]), ref["bw_X_ancestors"], atol=2e-4, rtol=1e-5)
+        assert torch.allclose(Hh.w_to_ref(bs["bwW"]), ref["bw_log_W"], atol=5e-4, rtol=1e-5)
+        assert torch.allclose(bs["lseW"].double().cpu(), torch.logsumexp(ref["bw_log_W"], 1), atol=5e-4, rtol=1e-5)
     assert torch.allclose(log["Xs"].double().cpu(), ref["Xs"], atol=2e-4, rtol=1e-5)
     assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
 
@@ -98,9 +114,12 @@ def test_free_running_indices(built_lib, case):
     if ref["idx_f"] is not None:
         idx = log["filter"]["idx"].permute(0, 2, 1).cpu().long()
         assert (idx != ref["idx_f"]).float().mean() == 0.0
-    if obj == "PSVO":
+    if obj in ("PSVO", "PSVOwR"):
         sel = log["bsim"]["sel"].permute(0, 2, 1).cpu().long()
         assert (sel != ref["idx_b"]).float().mean() == 0.0
+    if obj == "PSVOwR":
+        anc = log["bsim"]["anc"].permute(0, 2, 1).cpu().long()
+        assert (anc != ref["idx_r"]).float().mean() == 0.0
     assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
     assert torch.allclose(log["Xs"].double().cpu(), ref["Xs"], atol=2e-4, rtol=1e-5)
 
@@ -163,7 +182,7 @@ def _pairs(model, P):
     if not (model.use_bootstrap and model.use_2_q):
         out.append(("X0_transformer.W", model.X0_transformer_kernel, P["X0_transformer"][0]))
         out.append(("X0_transformer.b", model.X0_transformer_bias, P["X0_transformer"][1]))
-    if model.PSVO:
+    if model.PSVO or model.PSVOwR:
         dist("BSim_q_init", model.Bsim_q_init_dist); dist("q1_inv", model.q1_inv_dist)
         dist("BSim_q2", model.BSim_q2_dist)
     if model.bRNN is not None:
@@ -195,19 +214,23 @@ GRAD_CASES = CASES
 
 @pytest.mark.parametrize("case", GRAD_CASES, ids=lambda c: "-".join(map(str, c)))
 def test_filter_gradients(built_lib, case):
-    """d log_ZSMC / d(all parameters) for SVO / AESMC / IWAE / PSVO, teacher-forced indices."""
+    """d log_ZSMC / d(all parameters) for SVO / AESMC / IWAE / PSVO / PSVOwR, teacher-forced indices."""
     obj = case[0]
     FLAGS, model, smc, obs, noise = _setup(*case, seed=5)
     _, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
     teacher = {"idx_f": ref0["idx_f"]} if ref0["idx_f"] is not None else {}
-    if obj == "PSVO":
+    if obj in ("PSVO", "PSVOwR"):
         teacher["idx_b"] = ref0["idx_b"]
+    if obj == "PSVOwR":
+        teacher["idx_r"] = ref0["idx_r"]
     z_ref, P = _oracle_grads(model, FLAGS, obj, obs, noise, teacher)
     nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
     if "idx_f" in nz:
         nz.pop("u_f", None)
     if "sel_b" in nz:
         nz.pop("u_b", None)
+    if "anc_r" in nz:
+        nz.pop("u_r", None)
     model.zero_grad()
     z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
     z.backward()
