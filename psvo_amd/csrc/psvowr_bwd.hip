@@ -178,10 +178,10 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
         for (int i = tid; i < DX * N; i += NTB) dxs[i] = 0.f;
         for (int i = tid; i < nw * NA * NP; i += NTB) jacc[i] = 0.f;
         __syncthreads();
-        if (tid < N) {
-            const int p = a.anc[tb * N + tid];
+        for (int k = tid; k < N; k += NTB) {
+            const int p = a.anc[tb * N + k];
 #pragma unroll
-            for (int d = 0; d < DX; ++d) atomicAdd(&dxs[d * N + p], dxa[d * N + tid]);
+            for (int d = 0; d < DX; ++d) atomicAdd(&dxs[d * N + p], dxa[d * N + k]);
         }
         __syncthreads();
 
@@ -405,12 +405,12 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
 
         // ---- phase 2: per-sequence outputs of the step ----------------------------------------------------------------
         for (int i = tid; i < DX * N; i += NTB) dxa[i] = dxn[i];     // becomes d bwXanc_{t+1}
-        if (wave < 2 * DX) {   // wave w sums vector w of cacc over the chains
+        for (int v = wave; v < 2 * DX; v += nw) {   // one wave sums vector v of cacc over the chains
             float s = 0.f;
-            for (int i = lane; i < N; i += 64) s += cacc[wave * N + i];
+            for (int i = lane; i < N; i += 64) s += cacc[v * N + i];
             s = wave_sum(s);
             if (lane == 0) {
-                const int which = wave / DX, d = wave % DX;
+                const int which = v / DX, d = v % DX;
                 if (which == 0) {
                     a.dbmu2[tb * DX + d] = last ? 0.f : s;
                     if (last) a.dminit[(size_t)b * DX + d] = s;
@@ -512,7 +512,6 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
     long long items = (long long)a.N * M;
     int NTB = (int)(((items + 63) / 64) * 64);
     if (NTB > 512) NTB = 512;
-    if (a.N > NTB || 2 * DX > NTB / 64) return PSVO_ERR_UNSUPPORTED;
     const int nw = NTB / 64;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nw * (DX + 1) * NP +
                                         6 * DX * (size_t)a.N + 64);
