@@ -35,6 +35,7 @@ WORKLOADS = {
     "C3": ("PSVO", 32, 400, 128, 3, 1, 16, 32, 32),
     "C4": ("PSVO", 32, 200, 256, 2, 1, 16, 32, 32),
     "C5": ("PSVO", 8, 1000, 512, 4, 1, 16, 32, 32),
+    "C*wR": ("PSVOwR", 32, 200, 128, 2, 1, 16, 32, 32),     # C* sizes under the PSVOwR objective (not a headline line)
 }
 FP32_PEAK_TFLOPS = 157.3     # MI355X f32 vector peak == f32-input MFMA dense peak (MI355X_MICROARCH.md)
 EXP_PEAK = 9.8e12            # transcendental quarter rate, exp/s
@@ -49,8 +50,10 @@ def flop_model(Dx, Dy, N, M, H, E):
     # reverse passes: MLP forward recompute + input-gradient pass (2x), second pair pass (5 Dx + 6 per pair)
     f_filt_b = 2 * (mlp(Dx, Dx) + mlp(Dx, Dy)) + 40 * Dx + 12 * Dy + 20
     f_bsim_b = 2 * mlp(Dx, Dx) + 2 * M * (mlp(Dx, Dx) + mlp(Dx, Dy)) + M * N * (5 * Dx + 6) + M * (20 * Dx + 8 * Dy + 20)
+    # the PSVOwR kernels do the same per-item arithmetic as the PSVO ones (plus an O(N) cross-chain draw per step)
     return {"psvo_filter_forward": f_filt, "psvo_bsim_forward": f_bsim,
-            "psvo_filter_backward": f_filt_b, "psvo_bsim_backward": f_bsim_b}, M * N
+            "psvo_filter_backward": f_filt_b, "psvo_bsim_backward": f_bsim_b,
+            "psvo_bsimwr_forward": f_bsim, "psvo_bsimwr_backward": f_bsim_b}, M * N
 
 
 def fhn_batch(B, T, seed, device):
@@ -83,7 +86,8 @@ def build_objective(wl, device, seed=0):
     from psvo_amd.SMC.PSVO import PSVO
     from psvo_amd.SMC.SVO import SVO
     obj, B, T, N, Dx, Dy, M, H, Dh = wl
-    flags = dict(PSVO=False, SVO=False, AESMC=False, IWAE=False)
+    from psvo_amd.SMC.PSVOwR import PSVOwR
+    flags = dict(PSVO=False, SVO=False, AESMC=False, IWAE=False, PSVOwR=False)
     flags[obj] = True
     hs = str(H)
     FLAGS = Flags(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, batch_size=B, time=T,
@@ -91,7 +95,7 @@ def build_objective(wl, device, seed=0):
                   y_smoother_Dhs=str(Dh), X0_smoother_Dhs=str(Dh), **flags)
     torch.manual_seed(seed)
     model = SSM(FLAGS).to(device)
-    smc = {"PSVO": PSVO, "SVO": SVO, "AESMC": AESMC, "IWAE": IWAE}[obj](model, FLAGS)
+    smc = {"PSVO": PSVO, "SVO": SVO, "AESMC": AESMC, "IWAE": IWAE, "PSVOwR": PSVOwR}[obj](model, FLAGS)
     return FLAGS, model, smc
 
 

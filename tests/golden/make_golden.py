@@ -5,7 +5,7 @@ not installable), so these vectors are produced by the CPU oracle (oracle/psvo_o
 in this container -- PARITY UNPINNED w.r.t. the reference itself.  They pin the oracle against
 accidental change and give the GPU tests a second, file-based target.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case ...]
 """
 import os
 import sys
@@ -26,6 +26,7 @@ CASES = {
     "aesmc_mid": ("AESMC", 3, 10, 64, 4, 2, 1, 32, 8, True, True),
     "iwae_c1": ("IWAE", 1, 50, 4, 4, 2, 1, 32, 8, True, True),
     "svo_small": ("SVO", 2, 7, 16, 4, 2, 1, 16, 8, True, True),
+    "psvowr_small": ("PSVOwR", 2, 6, 12, 4, 2, 1, 16, 8, True, True),
 }
 
 
@@ -75,8 +76,8 @@ def run(fl, P, obs, noise):
     return z, log
 
 
-def main():
-    for name in CASES:
+def main(names=None):
+    for name in (names or CASES):
         fl, P, obs, noise = build(name)
         z, log = run(fl, P, obs, noise)
         out = {"log_ZSMC": z.detach().numpy(), "obs": obs.numpy()}
@@ -94,7 +95,7 @@ def main():
         g("grad", P)
         out.update(grads)
         for k in ("Xs", "X_prevs", "X_ancestors", "log_Ws", "idx_f", "bw_Xs", "f_log_probs", "g_log_probs",
-                  "bw_log_Omegas", "idx_b"):
+                  "bw_log_Omegas", "idx_b", "bw_X_ancestors", "bw_log_W", "idx_r"):
             if log.get(k) is not None:
                 out["out." + k] = log[k].detach().numpy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
@@ -102,4 +103,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])       # no arguments: regenerate every fixture

@@ -21,8 +21,9 @@ def _objective(obj):
     from psvo_amd.SMC.AESMC import AESMC
     from psvo_amd.SMC.IWAE import IWAE
     from psvo_amd.SMC.PSVO import PSVO
+    from psvo_amd.SMC.PSVOwR import PSVOwR
     from psvo_amd.SMC.SVO import SVO
-    return {"SVO": SVO, "PSVO": PSVO, "AESMC": AESMC, "IWAE": IWAE}[obj]
+    return {"SVO": SVO, "PSVO": PSVO, "AESMC": AESMC, "IWAE": IWAE, "PSVOwR": PSVOwR}[obj]
 
 
 @pytest.mark.parametrize("name", sorted(MG.CASES))
@@ -51,6 +52,9 @@ def test_golden_vectors(built_lib, name):
         assert (log["filter"]["idx"].permute(0, 2, 1).cpu().numpy() == ref["out.idx_f"]).all()
     if "out.idx_b" in ref.files:
         assert (log["bsim"]["sel"].permute(0, 2, 1).cpu().numpy() == ref["out.idx_b"]).all()
+    if "out.idx_r" in ref.files:
+        assert (log["bsim"]["anc"].permute(0, 2, 1).cpu().numpy() == ref["out.idx_r"]).all()
+        assert np.allclose(Hh.w_to_ref(log["bsim"]["bwW"].detach()).numpy(), ref["out.bw_log_W"], atol=5e-4)
     g = model.q1_tran.kernels[0].grad.double().cpu().numpy()
     gr = ref["grad.q1.layers.0.0"]
     assert np.abs(g - gr).max() <= 2e-3 * max(np.abs(gr).max(), 1e-6) + 1e-6

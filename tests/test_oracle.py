@@ -130,9 +130,11 @@ def test_linear_gaussian_ssm_matches_kalman_likelihood():
     assert abs(float(z) - ll / B) < 0.05, (float(z), ll / B)
 
 
-def test_oracle_autograd_matches_finite_differences():
+@pytest.mark.parametrize("objective", ["PSVO", "PSVOwR"])
+def test_oracle_autograd_matches_finite_differences(objective):
     """teacher-forced indices make log_ZSMC a smooth function of the parameters"""
-    fl = _flags("PSVO", n_particles=5, n_particles_for_BSim_proposal=3)
+    fl = _flags(objective, n_particles=5, n_particles_for_BSim_proposal=3)
+    Oracle = O.OBJECTIVES[objective]
     P = O.make_params(fl, seed=2, bias_scale=0.3)
     for k in P:
         if isinstance(P[k], dict) and "sigma_raw" in P[k]:
@@ -141,13 +143,15 @@ def test_oracle_autograd_matches_finite_differences():
     _, obs = O.fhn_synthetic(2, 4, seed=3)
     noise = O.make_noise(fl, 2, 4, seed=8)
     with torch.no_grad():
-        _, log = O.OraclePSVO(P, fl).get_log_ZSMC(obs, noise)
+        _, log = Oracle(P, fl).get_log_ZSMC(obs, noise)
     teacher = {**noise, "idx_f": log["idx_f"], "idx_b": log["idx_b"]}
+    if objective == "PSVOwR":
+        teacher["idx_r"] = log["idx_r"]
     targets = [P["q1"]["layers"][0][0], P["g"]["mu"][1], P["q1_inv"]["sigma_raw"], P["BSim_q2"]["mu"][0],
                P["bRNN"]["y_smoother"][0]["fw"][0]]
     for t in targets:
         t.requires_grad_(True)
-    z, _ = O.OraclePSVO(P, fl).get_log_ZSMC(obs, teacher)
+    z, _ = Oracle(P, fl).get_log_ZSMC(obs, teacher)
     grads = torch.autograd.grad(z, targets)
     for t, g in zip(targets, grads):
         flat = t.detach().view(-1)
@@ -155,9 +159,9 @@ def test_oracle_autograd_matches_finite_differences():
             old = float(flat[k])
             with torch.no_grad():
                 flat[k] = old + 1e-6
-                zp, _ = O.OraclePSVO(P, fl).get_log_ZSMC(obs, teacher)
+                zp, _ = Oracle(P, fl).get_log_ZSMC(obs, teacher)
                 flat[k] = old - 1e-6
-                zm, _ = O.OraclePSVO(P, fl).get_log_ZSMC(obs, teacher)
+                zm, _ = Oracle(P, fl).get_log_ZSMC(obs, teacher)
                 flat[k] = old
             fd = (float(zp) - float(zm)) / 2e-6
             assert abs(fd - float(g.view(-1)[k])) < 1e-5 * max(1.0, abs(fd)), (fd, float(g.view(-1)[k]))
@@ -171,11 +175,29 @@ def test_golden_fixture_regression(name):
     fl, P, obs, noise = MG.build(name)
     z, log = MG.run(fl, P, obs, noise)
     assert abs(float(z) - float(ref["log_ZSMC"])) < 1e-10
-    for k in ("Xs", "log_Ws", "bw_Xs", "bw_log_Omegas"):
+    for k in ("Xs", "log_Ws", "bw_Xs", "bw_log_Omegas", "bw_X_ancestors", "bw_log_W"):
         if "out." + k in ref.files:
             assert np.allclose(log[k].detach().numpy(), ref["out." + k], atol=1e-10)
-    for k in ("idx_f", "idx_b"):
+    for k in ("idx_f", "idx_b", "idx_r"):
         if "out." + k in ref.files:
             assert (log[k].numpy() == ref["out." + k]).all()
     g = P["q1"]["layers"][0][0].grad
     assert np.allclose(g.numpy(), ref["grad.q1.layers.0.0"], atol=1e-9)
+
+
+def test_psvowr_weight_closed_form():
+    """The HIP kernel writes bw_log_W = logsumexp_m(omega_raw) - phi_sel - log M (csrc/psvowr_fwd.hip); the oracle
+    restates the reference's expression (PSVOwR.py:135-142) term by term.  With the cross-chain draw teacher-forced
+    to the identity and M = 1 the weights collapse to Lambda + g - q of the single proposal draw, so that
+    log_ZSMC(M = 1) is an importance-sampling estimate whose value is independent of the sub-particle index."""
+    fl = _flags("PSVOwR", n_particles=6, n_particles_for_BSim_proposal=1)
+    P = O.make_params(fl, seed=4, bias_scale=0.2)
+    _, obs = O.fhn_synthetic(2, 5, seed=1)
+    noise = O.make_noise(fl, 2, 5, seed=9)
+    with torch.no_grad():
+        z, log = O.OraclePSVOwR(P, fl).get_log_ZSMC(obs, noise)
+    assert (log["idx_b"] == 0).all()                 # one sub-particle: nothing to choose
+    assert torch.isfinite(z)
+    # the cross-chain ancestors really index the selected sub-particles of the same step
+    idx = log["idx_r"].unsqueeze(-1).expand(-1, -1, -1, log["bw_Xs"].shape[-1])
+    assert torch.equal(log["bw_X_ancestors"], torch.gather(log["bw_Xs"], 1, idx))
