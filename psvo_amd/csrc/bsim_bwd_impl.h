@@ -25,6 +25,8 @@
 #include "common.h"
 
 namespace psvo {
+PSVO_TIMERS_DEFINE(bsim_bwd)
+
 
 struct BsimBwdArgs {
     int B, T, N;
@@ -176,18 +178,20 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
     const float aw = valid ? a.dscore[(size_t)b * N + n] : 0.f;  // d loss / d score of this chain
 
     // ---- forward-tile staging (identical image to the forward kernel) -----------------------------------
-    float st[kMaxStage][DX + 1];
+    // raw values are loaded at the top of a step and only scaled / written to LDS at its end, so that nothing
+    // in between waits for the global loads
+    float st[kMaxStage][DX + 1], st_l = 0.f;
     auto stage_load = [&](int tt) {
         const size_t tb = (size_t)tt * B + b;
-        const float l = a.lse[tb];
+        st_l = a.lse[tb];
 #pragma unroll
         for (int r = 0; r < kMaxStage; ++r) {
             const int j = tid + r * NTB;
             if (j < NP) {
                 const int jc = j < N ? j : N - 1;
 #pragma unroll
-                for (int d = 0; d < DX; ++d) st[r][d] = a.Fm[(tb * DX + d) * N + jc] * rp[d];
-                st[r][DX] = j < N ? (a.logW[tb * N + jc] - l) * kLog2e : ninf;
+                for (int d = 0; d < DX; ++d) st[r][d] = a.Fm[(tb * DX + d) * N + jc];
+                st[r][DX] = a.logW[tb * N + jc];
             }
         }
     };
@@ -196,16 +200,20 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         for (int r = 0; r < kMaxStage; ++r) {
             const int j = tid + r * NTB;
             if (j < NP) {
+                float F[DX];
+#pragma unroll
+                for (int d = 0; d < DX; ++d) F[d] = st[r][d] * rp[d];
+                const float W = j < N ? (st[r][DX] - st_l) * kLog2e : ninf;
                 if constexpr (DX <= 3) {
                     float4 v;
-                    v.x = st[r][0];
-                    v.y = DX > 1 ? st[r][DX > 1 ? 1 : 0] : 0.f;
-                    v.z = DX > 2 ? st[r][DX > 2 ? 2 : 0] : 0.f;
-                    v.w = st[r][DX];
+                    v.x = F[0];
+                    v.y = DX > 1 ? F[DX > 1 ? 1 : 0] : 0.f;
+                    v.z = DX > 2 ? F[DX > 2 ? 2 : 0] : 0.f;
+                    v.w = W;
                     *reinterpret_cast<float4*>(buf + j * PS) = v;
                 } else {
-                    *reinterpret_cast<float4*>(buf + j * PS) = make_float4(st[r][0], st[r][1], st[r][2], st[r][3]);
-                    *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(st[r][4], 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(buf + j * PS) = make_float4(F[0], F[1], F[2], F[3]);
+                    *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(W, 0.f, 0.f, 0.f);
                 }
             }
         }
@@ -252,7 +260,9 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
     const int nqh = (nq + HS - 1) / HS;   // ... per chain half
     const int e0 = hpart * nqh, e1 = min(nq, (hpart + 1) * nqh);
 
+    SEC_INIT(bsim_bwd)
     for (int t = 0; t < T; ++t) {
+        SEC(0);
         const size_t tb = (size_t)t * B + b;
         const bool last = (t == T - 1), first = (t == 0);
         const float* cur = tile + ((t + 1) & 1) * NP * PS;  // tile(t-1), valid for t >= 1
@@ -261,6 +271,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 
         // ---- recompute the proposal ---------------------------------------------------------------------
         if (t + 1 < T) load_step(t + 1, nxt_in);
+        SEC(1);   // issue of the prefetch loads
         float xp[DX], eps[DX], bm[DX], mu1[DX], mu[DX], x[DX], y[DY];
         const int sel = cur_in.sel;
 #pragma unroll
@@ -288,6 +299,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 #pragma unroll
         for (int d = 0; d < DX; ++d) dxt[d] = h0 ? issel * dX[d] : 0.f;  // dxt: this lane's PARTIAL of d x~_m
 
+        SEC(2);   // proposal recompute, coefficients
         // ---- filter term: second pass over the forward tile -------------------------------------------------
 #ifdef PSVO_EXP_NOPAIR
         if (false) {
@@ -366,6 +378,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                     }
                 }
             }
+            SEC(3);   // pair loop + butterflies
             // merge the quad's four j-slices; lane q keeps sub-particle i == q
             float Uo[DX], Vo[DX];
 #pragma unroll
@@ -406,6 +419,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
             }
         }
 
+        SEC(4);   // quad merges
         // ---- f(x_{t+1} | x~), g(y_t | x~) ------------------------------------------------------------------------
         float dxp_part[DX];
 #pragma unroll
@@ -461,6 +475,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
             else MG::template bwd_input_part<HS>(wg, hpart, x, dGo, dxt);
         }
 
+        SEC(5);   // MLP_f / MLP_g forward + input gradients, row stores
         // ---- reduce over the chain's M sub-particles ------------------------------------------------------------
         float dmu[DX], sce[DX], dxp[DX], dim[DX];
 #pragma unroll
@@ -512,6 +527,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 #pragma unroll
         for (int d = 0; d < DX; ++d) dX[d] = dxp[d];
 
+        SEC(6);   // chain reductions, MLP_q1inv input gradient
         // ---- workgroup reductions: d bmu2[t] / d minit, d imean; flush d Fm / d logW partials ---------------------------
         if (m == 0 && h0) {
 #pragma unroll
@@ -552,9 +568,11 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                 else a.dlogW_part[(tb * nblk + blk) * N + j] = 0.f;
             }
         }
+        SEC(7);   // barrier, workgroup sums, d Fm / d logW flush
         if (t + 1 < T && t >= 1) stage_store(nxt);
         cur_in = nxt_in;
         __syncthreads();
+        SEC(8);   // tile store + barrier
     }
 
     // ---- scalar accumulators: reduce over the workgroup ---------------------------------------------------------------

@@ -18,6 +18,8 @@
 #include "common.h"
 
 namespace psvo {
+PSVO_TIMERS_DEFINE(bsim_fwd)
+
 
 struct BsimArgs {
     int B, T, N;
@@ -67,7 +69,8 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int NTB = blockDim.x;
     const int B = a.B, T = a.T, N = a.N;
-    const int NP = (N + 3) & ~3;
+    // forward tile padded (W' = -inf) so that every half-slice of a quad lane is a whole number of 4-entry blocks
+    const int NP = ((N + 16 * HS - 1) / (16 * HS)) * (16 * HS);
     const int b = blockIdx.y;
     constexpr int G = M * HS;  // lanes per chain
     const int cpb = NTB / G;
@@ -132,36 +135,42 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
     const float ninf = -__builtin_huge_valf();
 
     // ---- forward-tile staging -----------------------------------------------------------------
-    float st[kMaxStage][DX + 1];
-    auto stage_load = [&](int tt) {  // global -> registers, forward step tt
+    // The global loads of step t-2's tile are issued at the top of step t and only *consumed* (scaled and
+    // written to LDS) at its end: nothing between depends on them, so their latency hides behind the step.
+    float st[kMaxStage][DX + 1], st_l = 0.f;
+    auto stage_load = [&](int tt) {  // global -> registers (raw), forward step tt
         const size_t tb = (size_t)tt * B + b;
-        const float l = a.lse[tb];
+        st_l = a.lse[tb];
 #pragma unroll
         for (int r = 0; r < kMaxStage; ++r) {
             const int j = tid + r * NTB;
             if (j < NP) {
                 const int jc = j < N ? j : N - 1;
 #pragma unroll
-                for (int d = 0; d < DX; ++d) st[r][d] = a.Fm[(tb * DX + d) * N + jc] * rp[d];
-                st[r][DX] = j < N ? (a.logW[tb * N + jc] - l) * kLog2e : ninf;
+                for (int d = 0; d < DX; ++d) st[r][d] = a.Fm[(tb * DX + d) * N + jc];
+                st[r][DX] = a.logW[tb * N + jc];
             }
         }
     };
-    auto stage_store = [&](float* buf) {  // registers -> LDS
+    auto stage_store = [&](float* buf) {  // registers -> LDS: F' = Fm * rho, W' = (logW - lse) * log2(e)
 #pragma unroll
         for (int r = 0; r < kMaxStage; ++r) {
             const int j = tid + r * NTB;
             if (j < NP) {
+                float F[DX];
+#pragma unroll
+                for (int d = 0; d < DX; ++d) F[d] = st[r][d] * rp[d];
+                const float W = j < N ? (st[r][DX] - st_l) * kLog2e : ninf;
                 if constexpr (DX <= 3) {
                     float4 v;
-                    v.x = st[r][0];
-                    v.y = DX > 1 ? st[r][DX > 1 ? 1 : 0] : 0.f;
-                    v.z = DX > 2 ? st[r][DX > 2 ? 2 : 0] : 0.f;
-                    v.w = st[r][DX];
+                    v.x = F[0];
+                    v.y = DX > 1 ? F[DX > 1 ? 1 : 0] : 0.f;
+                    v.z = DX > 2 ? F[DX > 2 ? 2 : 0] : 0.f;
+                    v.w = W;
                     *reinterpret_cast<float4*>(buf + j * PS) = v;
                 } else {
-                    *reinterpret_cast<float4*>(buf + j * PS) = make_float4(st[r][0], st[r][1], st[r][2], st[r][3]);
-                    *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(st[r][4], 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(buf + j * PS) = make_float4(F[0], F[1], F[2], F[3]);
+                    *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(W, 0.f, 0.f, 0.f);
                 }
             }
         }
@@ -195,7 +204,9 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
     for (int d = 0; d < DX; ++d) xp[d] = 0.f;
     float score = 0.f;
 
+    SEC_INIT(bsim_fwd)
     for (int t = T - 1; t >= 0; --t) {
+        SEC(0);   // loop overhead / barrier tail
         const size_t tb = (size_t)t * B + b;
         const float* cur = tile + ((T - 1 - t) & 1) * NP * PS;
         float* nxt = tile + ((T - t) & 1) * NP * PS;
@@ -206,6 +217,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         if (t >= 1) load_inputs(t - 1, eps_n, bmu_n, obs_n, u_n, sel_n);
         if (t >= 2) stage_load(t - 2);
 
+        SEC(1);   // issue of the prefetch loads
         // ---- proposal ---------------------------------------------------------------------------
         float x[DX], q_lp;
         if (last) {
@@ -241,6 +253,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
             q_lp = diag_lp<DX>(x, mu, pic, kq);
         }
 
+        SEC(2);   // MLP_q1inv + proposal
         // ---- f(x_{t+1} | x~), g(y_t | x~) ------------------------------------------------------------
         float phi = 0.f;
         if (!last) {
@@ -264,6 +277,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         }
         const float g_lp = diag_lp<DY>(obs_c, gm, isg, kg);
 
+        SEC(3);   // MLP_f, MLP_g, densities
         // ---- filter term: logsumexp_j( log f(x~ | X_{t-1}[j]) + W^_{t-1}[j] ) -----------------------
         float lam;
         if (t >= 1) {
@@ -275,88 +289,78 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xq[i][d] = t4[i];
             }
-            float mx[4], sm[4];
+            // The lane walks its quad-slice of the forward tile in blocks of JB entries (4 pairs per entry:
+            // the quad's four sub-particles).  Phase A forms every v of the block with packed f32 math
+            // (v_pk_add_f32 / v_pk_fma_f32 / v_pk_max_f32: sub-particles (0,1) and (2,3) share an instruction)
+            // and the block maximum; phase B rescales the running sums ONCE per block and adds the block's
+            // exponentials.  At C* one block covers the lane's whole slice, so no rescaling remains.
+            f2 xa[DX], xb[DX];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                mx[i] = ninf;
-                sm[i] = 0.f;
+            for (int d = 0; d < DX; ++d) {
+                xa[d] = f2{xq[0][d], xq[1][d]};
+                xb[d] = f2{xq[2][d], xq[3][d]};
             }
-            // lane walks j = q, q+4, ...; chunks of 4 such j per online-lse update
-            const int nq = NP >> 2;               // forward-tile entries per quad lane
-            const int nqh = (nq + HS - 1) / HS;   // ... per half
-            const int e1 = min(nq, (hpart + 1) * nqh);
-            int jj = hpart * nqh;
-            for (; jj + 4 <= e1; jj += 4) {
-                float v[4][4];
+            f2 mxa = f2{ninf, ninf}, mxb = mxa, sma = f2{0.f, 0.f}, smb = sma;
+            const int nqh = (NP >> 2) / HS;       // forward-tile entries per quad lane and half (multiple of 4)
+            const int j0 = hpart * nqh;
+            auto block = [&](auto jb_tag, int k0) {
+                constexpr int JB = decltype(jb_tag)::value;
+                f2 va[JB], vb[JB];
+                f2 bma = f2{ninf, ninf}, bmb = bma;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float* p = cur + ((jj + c) * 4 + q) * PS;
+                for (int c = 0; c < JB; ++c) {
+                    const float* p = cur + ((j0 + k0 + c) * 4 + q) * PS;
                     float F[DX], W;
                     if constexpr (DX <= 3) {
-                        const float4 e = *reinterpret_cast<const float4*>(p);
-                        F[0] = e.x;
-                        if (DX > 1) F[DX > 1 ? 1 : 0] = e.y;
-                        if (DX > 2) F[DX > 2 ? 2 : 0] = e.z;
-                        W = e.w;
+                        const float4 sl = *reinterpret_cast<const float4*>(p);
+                        F[0] = sl.x;
+                        if (DX > 1) F[DX > 1 ? 1 : 0] = sl.y;
+                        if (DX > 2) F[DX > 2 ? 2 : 0] = sl.z;
+                        W = sl.w;
                     } else {
-                        const float4 e = *reinterpret_cast<const float4*>(p);
-                        F[0] = e.x; F[1] = e.y; F[2] = e.z; F[3] = e.w;
+                        const float4 sl = *reinterpret_cast<const float4*>(p);
+                        F[0] = sl.x; F[1] = sl.y; F[2] = sl.z; F[3] = sl.w;
                         W = p[4];
                     }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float acc = W;
-#pragma unroll
-                        for (int d = 0; d < DX; ++d) {
-                            const float df = xq[i][d] - F[d];
-                            acc = fmaf(-df, df, acc);
-                        }
-                        v[i][c] = acc;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float cm = fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3]));
-                    const float nm = fmaxf(mx[i], cm);
-                    // nm == -inf only if every term so far is -inf: keep s = 0 without NaNs
-                    const float base = (nm == ninf) ? 0.f : nm;
-                    float s = sm[i] * exp2_fast(mx[i] - base);
-                    s += exp2_fast(v[i][0] - base);
-                    s += exp2_fast(v[i][1] - base);
-                    s += exp2_fast(v[i][2] - base);
-                    s += exp2_fast(v[i][3] - base);
-                    sm[i] = s;
-                    mx[i] = nm;
-                }
-            }
-            for (; jj < e1; ++jj) {  // remainder entries
-                const float* p = cur + (jj * 4 + q) * PS;
-                float F[DX], W;
-                if constexpr (DX <= 3) {
-                    const float4 e = *reinterpret_cast<const float4*>(p);
-                    F[0] = e.x;
-                    if (DX > 1) F[DX > 1 ? 1 : 0] = e.y;
-                    if (DX > 2) F[DX > 2 ? 2 : 0] = e.z;
-                    W = e.w;
-                } else {
-                    const float4 e = *reinterpret_cast<const float4*>(p);
-                    F[0] = e.x; F[1] = e.y; F[2] = e.z; F[3] = e.w;
-                    W = p[4];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float acc = W;
+                    f2 la = f2{W, W}, lb = la;
 #pragma unroll
                     for (int d = 0; d < DX; ++d) {
-                        const float df = xq[i][d] - F[d];
-                        acc = fmaf(-df, df, acc);
+                        const f2 Fd = f2{F[d], F[d]};
+                        const f2 ua = xa[d] - Fd, ub = xb[d] - Fd;
+                        la = pk_fma(-ua, ua, la);
+                        lb = pk_fma(-ub, ub, lb);
                     }
-                    const float nm = fmaxf(mx[i], acc);
-                    const float base = (nm == ninf) ? 0.f : nm;
-                    sm[i] = sm[i] * exp2_fast(mx[i] - base) + exp2_fast(acc - base);
-                    mx[i] = nm;
+                    va[c] = la;
+                    vb[c] = lb;
+                    bma = pk_max(bma, la);
+                    bmb = pk_max(bmb, lb);
                 }
+                const f2 nma = pk_max(mxa, bma), nmb = pk_max(mxb, bmb);
+                // nm == -inf only if every term so far is -inf: keep s = 0 without NaNs
+                const f2 ba = f2{nma.x == ninf ? 0.f : nma.x, nma.y == ninf ? 0.f : nma.y};
+                const f2 bb = f2{nmb.x == ninf ? 0.f : nmb.x, nmb.y == ninf ? 0.f : nmb.y};
+                const f2 ra = mxa - ba, rb = mxb - bb;
+                sma = sma * f2{exp2_fast(ra.x), exp2_fast(ra.y)};
+                smb = smb * f2{exp2_fast(rb.x), exp2_fast(rb.y)};
+#pragma unroll
+                for (int c = 0; c < JB; ++c) {
+                    const f2 da = va[c] - ba, db = vb[c] - bb;
+                    sma += f2{exp2_fast(da.x), exp2_fast(da.y)};
+                    smb += f2{exp2_fast(db.x), exp2_fast(db.y)};
+                }
+                mxa = nma;
+                mxb = nmb;
+            };
+            int k0 = 0;                           // (nqh is wave-uniform and a multiple of 4)
+            for (; k0 + 16 <= nqh; k0 += 16) block(std::integral_constant<int, 16>{}, k0);
+            if (nqh - k0 >= 8) {
+                block(std::integral_constant<int, 8>{}, k0);
+                k0 += 8;
             }
+            if (nqh - k0 >= 4) block(std::integral_constant<int, 4>{}, k0);
+            SEC(4);   // pair loop
+            const float mx[4] = {mxa.x, mxa.y, mxb.x, mxb.y};
+            const float sm[4] = {sma.x, sma.y, smb.x, smb.y};
             // merge the four j-slices of the quad; lane q keeps sub-particle i == q
             float lm = ninf, ls = 0.f;
 #pragma unroll
@@ -381,6 +385,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
             lam = diag_lp<DX>(x, im, i_isig, kiota);  // t = 0: q0 / f density at mu_0 (PSVO.py:169-175)
         }
 
+        SEC(5);   // quad / half merges, lam2
         // ---- omega, normalise over the M sub-particles, draw one ---------------------------------------
         const float om_raw = lam + phi + g_lp - q_lp;
         const float omx = group_max<M>(om_raw);
@@ -403,6 +408,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         for (int d = 0; d < DX; ++d) xs[d] = __shfl(x[d], src);
         const float om_s = __shfl(omega, src);
         const float phi_s = __shfl(phi, src);
+        SEC(6);   // normalise over M, draw
         const float g_s = __shfl(g_lp, src);
         const float q_s = __shfl(q_lp, src);
         const float lam_s = __shfl(lam, src);
@@ -430,8 +436,10 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         u_c = u_n;
         sel_c = sel_n;
 
+        SEC(7);   // gather of the selected sub-particle, output stores
         if (t >= 2) stage_store(nxt);
         __syncthreads();
+        SEC(8);   // tile store + barrier
     }
     if (valid && lead) a.score[(size_t)b * N + n] = score;
 }
@@ -441,10 +449,10 @@ static int launch_bsim(const BsimArgs& a, hipStream_t stream) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
     constexpr int PS = TileSlot<DX>::kFloats;
-    const int NP = (a.N + 3) & ~3;
     // fewer than two waves per SIMD (1024 SIMDs) with one lane per (chain, m): spread each chain over 2M lanes
     const long long waves1 = ((long long)a.B * a.N * M + 63) / 64;
     const int HS = (waves1 < 2048 && 2 * M <= 64 && (H / 2) % 4 == 0) ? 2 : 1;
+    const int NP = ((a.N + 16 * HS - 1) / (16 * HS)) * (16 * HS);
     int NTB = ((a.N * M * HS + 63) / 64) * 64;
     if (NTB > 256) NTB = 256;
     const int cpb = NTB / (M * HS);

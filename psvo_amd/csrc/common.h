@@ -1,5 +1,6 @@
 // Device-side helpers shared by the filter and backward-simulation kernels (gfx950 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,9 +23,48 @@ inline int launch_status() {
     return e == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Section timers (diagnostic builds only: tools/section_timers.py compiles one translation unit with
+// -DPSVO_SECTION_TIMERS into a separate library).  Lane 0 of workgroup (0,0) accumulates the shader-clock
+// cycles between consecutive SEC(i) marks of a persistent kernel; the product library has none of this.
+// ---------------------------------------------------------------------------------------------
+#ifdef PSVO_SECTION_TIMERS
+#define PSVO_TIMERS_DEFINE(name)                                                                        \
+    __device__ unsigned long long g_sec_##name[32];                                                       \
+    extern "C" int psvo_debug_timers_##name(unsigned long long* out, int reset) {                         \
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sec_##name), 32 * sizeof(unsigned long long)) != hipSuccess) \
+            return -1;                                                                                    \
+        if (reset) {                                                                                      \
+            unsigned long long z[32] = {0};                                                               \
+            if (hipMemcpyToSymbol(HIP_SYMBOL(g_sec_##name), z, sizeof(z)) != hipSuccess) return -1;       \
+        }                                                                                                 \
+        return 0;                                                                                         \
+    }
+#define SEC_INIT(name)                                                                          \
+    unsigned long long* const _sec = g_sec_##name;                                              \
+    const bool _rec = (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);                 \
+    unsigned long long _tp = clock64();
+#define SEC(i)                                   \
+    do {                                         \
+        const unsigned long long _tn = clock64(); \
+        if (_rec) _sec[i] += _tn - _tp;          \
+        _tp = _tn;                               \
+    } while (0)
+#else
+#define PSVO_TIMERS_DEFINE(name)
+#define SEC_INIT(name)
+#define SEC(i)
+#endif
+
 // v_exp_f32 / v_log_f32 are base-2 on CDNA; keep hot loops in the log2 domain.
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }
+
+// Packed f32 pairs: gfx950 executes v_pk_{add,mul,fma,max}_f32 on two floats per lane at the rate of one
+// scalar VALU op (this is where the 157.3 TFLOP/s f32 vector peak comes from).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 pk_max(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
 
 // ---------------------------------------------------------------------------------------------
 // One-hidden-layer MLP with weights staged in LDS, read as wave-uniform float4 broadcasts.

@@ -16,6 +16,8 @@
 #include "common.h"
 
 namespace psvo {
+PSVO_TIMERS_DEFINE(filter_bwd)
+
 
 struct FilterBwdArgs {
     int B, T, N;
@@ -143,33 +145,49 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
     auto load_anc = [&](int t) -> int {  // ancestor of particle n at step t (its parent lives at t-1)
         return (t >= 1 && a.resample) ? a.idx[((size_t)(t - 1) * B + b) * N + n] : n;
     };
+    // load_step only ISSUES loads into raw registers: every select / add on the loaded values happens when the
+    // step consumes them, one whole step later, so no s_waitcnt lands in the prefetch.  (Upstream partials with
+    // nparts > 1 are summed here with dependent adds -- the host wrapper passes them already folded, nparts = 1.)
+    const bool one_part = (a.nparts == 1);
     auto load_step = [&](int t, int anc, float (&sx)[DX], float (&se)[DX], float (&sm2)[DX], float (&sy)[DY],
                          float (&smean1)[DX], float (&sfmean)[DX], float (&sdfm)[DX], float (&ssc)[4]) {
         const size_t tb = (size_t)t * B + b;
+        const size_t tp = (t == 0) ? tb : tb - B;              // (t = 0 has no parent: value replaced at use)
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
             sx[d] = a.X[(tb * DX + d) * N + n];
             se[d] = a.eps[(tb * DX + d) * N + n];
             sm2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
-            const size_t tp = (t == 0) ? tb : tb - B;          // (t = 0 has no parent: value replaced below)
-            const float gf = a.Fm[(tp * DX + d) * N + anc];
-            const float gp = a.bootstrap ? gf : a.P1[(tp * DX + d) * N + anc];
-            sfmean[d] = (t == 0) ? fm0r[d] : gf;
-            smean1[d] = (t == 0) ? m0r[d] : gp;
-            float ext = 0.f;
-            if (a.dFm_ext)
-                for (int p = 0; p < a.nparts; ++p) ext += a.dFm_ext[((tb * a.nparts + p) * DX + d) * N + n];
-            sdfm[d] = ext;
+            sfmean[d] = a.Fm[(tp * DX + d) * N + anc];
+            smean1[d] = a.bootstrap ? 0.f : a.P1[(tp * DX + d) * N + anc];
+            if (a.dFm_ext) {
+                if (one_part) {
+                    sdfm[d] = a.dFm_ext[(tb * DX + d) * N + n];
+                } else {
+                    float ext = 0.f;
+                    for (int p = 0; p < a.nparts; ++p) ext += a.dFm_ext[((tb * a.nparts + p) * DX + d) * N + n];
+                    sdfm[d] = ext;
+                }
+            } else {
+                sdfm[d] = 0.f;
+            }
         }
 #pragma unroll
         for (int k = 0; k < DY; ++k) sy[k] = a.obs[tb * DY + k];
         ssc[0] = a.logW[tb * N + n];
         ssc[1] = a.lse[tb];
         ssc[2] = a.dlse ? a.dlse[tb] : 0.f;
-        float ext = 0.f;
-        if (a.dlogW_ext)
-            for (int p = 0; p < a.nparts; ++p) ext += a.dlogW_ext[(tb * a.nparts + p) * N + n];
-        ssc[3] = ext;
+        if (a.dlogW_ext) {
+            if (one_part) {
+                ssc[3] = a.dlogW_ext[tb * N + n];
+            } else {
+                float ext = 0.f;
+                for (int p = 0; p < a.nparts; ++p) ext += a.dlogW_ext[(tb * a.nparts + p) * N + n];
+                ssc[3] = ext;
+            }
+        } else {
+            ssc[3] = 0.f;
+        }
     };
     float c_x[DX], c_e[DX], c_m2[DX], c_y[DY], c_mean1[DX], c_fmean[DX], c_dfm[DX], c_sc[4];
     int c_anc = load_anc(T - 1);
@@ -177,7 +195,9 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
     load_step(T - 1, c_anc, c_x, c_e, c_m2, c_y, c_mean1, c_fmean, c_dfm, c_sc);
     __syncthreads();
 
+    SEC_INIT(filter_bwd)
     for (int t = T - 1; t >= 0; --t) {
+        SEC(0);
         const size_t tb = (size_t)t * B + b;
         const bool first = (t == 0);
         const BStepK<DX> K = first ? K0 : K1;
@@ -197,6 +217,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
             load_step(t - 1, n_anc, n_x, n_e, n_m2, n_y, n_mean1, n_fmean, n_dfm, n_sc);
             anc_next = load_anc(t - 2);
         }
+        SEC(1);   // issue of the prefetch loads
         float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX];
         const int anc = c_anc;
 #pragma unroll
@@ -204,8 +225,9 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
             x[d] = c_x[d];
             e[d] = c_e[d];
             m2[d] = c_m2[d];
-            mean1[d] = c_mean1[d];
-            fmean[d] = c_fmean[d];
+            // parents: gathered MLP outputs of step t-1 (bootstrap: MLP_q1 == MLP_f), or the t = 0 features
+            fmean[d] = first ? fm0r[d] : c_fmean[d];
+            mean1[d] = first ? m0r[d] : (a.bootstrap ? c_fmean[d] : c_mean1[d]);
         }
 #pragma unroll
         for (int k = 0; k < DY; ++k) y[k] = c_y[k];
@@ -224,6 +246,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
         if (!valid) dlw = 0.f;
         dlnw = first ? 0.f : dlw;
 
+        SEC(2);   // d logW
         // ---- emission ---------------------------------------------------------------------------
         float dx[DX];
 #pragma unroll
@@ -240,6 +263,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
             }
             MG::template bwd_input<kRolled>(wg, x, dgm, dx);
         }
+        SEC(3);   // MLP_g forward + input gradient
         // ---- transition and proposal densities ------------------------------------------------------
         float dfmean[DX];
 #pragma unroll
@@ -277,8 +301,10 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
                 if (!a.bootstrap) a.dF[(tb * DX + d) * N + n] = dFn[d];
             }
         }
+        SEC(4);   // densities, scatter targets from LDS, row stores
         MQ::template bwd_input<kRolled>(wq1, x, dPn, dx);
         if (!a.bootstrap) MQ::template bwd_input<kRolled>(wfm, x, dFn, dx);
+        SEC(5);   // MLP_q1 (/ MLP_f) input gradient
 
         // ---- x = mu + c eps, mu = c (mean1/s1 + mu2/s2) ----------------------------------------------------
         float dmean1[DX];
@@ -299,6 +325,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
                 dmean1[d] = dmu;
             }
         }
+        SEC(6);   // PoG gradient, block sums of d mu2
         // ---- gather backward: scatter-add into the parents (SVO.py:255-257) ------------------------------
         if (!first) {
             if (valid) {
@@ -323,6 +350,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
                 }
             }
         }
+        SEC(7);   // LDS scatter-add
         if (t >= 1) {
             c_anc = n_anc;
 #pragma unroll
@@ -341,6 +369,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
             acc[AC::kSet + i] += first ? 0.f : inc[i];
         }
         __syncthreads();
+        SEC(8);   // register rotation (waits for the prefetch) + barrier
     }
 
     // ---- per-sequence scalar accumulators ---------------------------------------------------------------

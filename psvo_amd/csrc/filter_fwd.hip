@@ -11,6 +11,8 @@
 #include "common.h"
 
 namespace psvo {
+PSVO_TIMERS_DEFINE(filter_fwd)
+
 
 struct FilterArgs {
     int B, T, N;
@@ -141,7 +143,9 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
     constexpr int kWeights = MQ::kSize + MG::kSize;
     constexpr bool kOpaque = (MAXT > 256) ? (kWeights > 120) : (kWeights > 330);
 
+    SEC_INIT(filter_fwd)
     for (int t = 0; t < T; ++t) {
+        SEC(0);
         const size_t tb = (size_t)t * B + b;
         const StepK<DX> K = (t == 0) ? K0 : K1;
         int zo = 0;
@@ -154,6 +158,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
         int idx_n = 0;
         if (t + 1 < T) load_inputs(t + 1, eps_n, mu2_n, obs_n, u_n, idx_n);
 
+        SEC(1);   // issue of the prefetch loads
         // ---- proposal: product of two diagonal Gaussians on *scales* (SVO.py:186-197) ----------
         float mu[DX], x[DX];
 #pragma unroll
@@ -164,6 +169,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
         const float q_lp = diag_lp<DX>(x, mu, K.ic, K.lq);
         const float f_lp = diag_lp<DX>(x, fmean, K.ifs, K.lf);
 
+        SEC(2);   // proposal, q / f densities
         // ---- emission ------------------------------------------------------------------------
         float gm[DY];
         MG::template eval<kOpaque>(wg_t, x, gm);
@@ -172,6 +178,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
         float lw = f_lp + g_lp - q_lp + lnw;
         if (!valid) lw = ninf;
 
+        SEC(3);   // MLP_g, weight
         // ---- next-step proposal / transition means of every pre-resampling particle -----------
         float p1[DX], fm[DX];
         MQ::template eval<kOpaque>(wq1_t, x, p1);
@@ -191,6 +198,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
             a.logW[tb * N + n] = lw;
         }
 
+        SEC(4);   // MLP_q1 (/ MLP_f), history stores
         // ---- log-sum-exp over particles and multinomial ancestors (SVO.py:266-300) -------------
         const float mx = block_max(lw, red, 0, wave, lane, nw);
         const float w = valid ? expf(lw - mx) : 0.f;
@@ -214,6 +222,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
         const float lse_t = mx + logf(total);
         if (tid == 0) a.lse[tb] = lse_t;
 
+        SEC(5);   // block max, exp, scan, total
         if (a.resample) {
             cdf[tid] = sc;
 #pragma unroll
@@ -223,6 +232,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
                 if (!a.bootstrap) sf[d * NT + tid] = fm[d];
             }
             __syncthreads();
+            SEC(6);   // stage particles / CDF in LDS + barrier
             int idx;
             if (a.idx_in) {
                 idx = idx_c;
@@ -248,6 +258,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
                 for (int d = 0; d < DX; ++d) a.Xanc[(tb * DX + d) * N + n] = x[d];
             }
             lnw = neg_logN;
+            SEC(7);   // CDF search, gather, ancestor stores
             __syncthreads();  // staged tiles are rewritten next step
         } else {
 #pragma unroll
