@@ -115,7 +115,6 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
     using MG = MlpLds<DX, H, DY>;
     using AC = BAcc<DX, DY>;
     constexpr int PS = BTileSlot<DX>::kFloats;
-    constexpr int kMaxStage = 4;
     constexpr bool kRolled = true;
     constexpr int NA = DX + 1;  // per-j accumulators: dF (DX) and dW
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -123,7 +122,10 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NTB = blockDim.x, nwv = NTB >> 6;
     const int B = a.B, T = a.T, N = a.N;
-    const int NP = (N + 3) & ~3;
+    // forward tile padded (W' = -inf: zero weight) to whole chunks of CH entries per quad lane and half, so the
+    // walk needs no per-entry predication and the LDS reads of a chunk are issued back to back
+    constexpr int kPad = 4 * CH * HS;
+    const int NP = ((N + kPad - 1) / kPad) * kPad;
     const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
     constexpr int G = M * HS;
     constexpr int NS = (HS == 2) ? 3 : 4;  // butterfly stages (quads that share a forward-particle range)
@@ -179,43 +181,45 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 
     // ---- forward-tile staging (identical image to the forward kernel) -----------------------------------
     // raw values are loaded at the top of a step and only scaled / written to LDS at its end, so that nothing
-    // in between waits for the global loads
-    float st[kMaxStage][DX + 1], st_l = 0.f;
-    auto stage_load = [&](int tt) {
-        const size_t tb = (size_t)tt * B + b;
-        st_l = a.lse[tb];
+    // in between waits for the global loads.  Only the first NTB tile slots are prefetched through registers
+    // (N <= 256: the latency-bound regime); the remaining slots of a larger tile are copied at store time.
+    float st[DX + 1], st_l = 0.f;
+    int st_t = 0;
+    auto put_slot = [&](float* buf, int j, const float (&raw)[DX + 1], float l) {
+        float F[DX];
 #pragma unroll
-        for (int r = 0; r < kMaxStage; ++r) {
-            const int j = tid + r * NTB;
-            if (j < NP) {
-                const int jc = j < N ? j : N - 1;
-#pragma unroll
-                for (int d = 0; d < DX; ++d) st[r][d] = a.Fm[(tb * DX + d) * N + jc];
-                st[r][DX] = a.logW[tb * N + jc];
-            }
+        for (int d = 0; d < DX; ++d) F[d] = raw[d] * rp[d];
+        const float W = j < N ? (raw[DX] - l) * kLog2e : ninf;
+        if constexpr (DX <= 3) {
+            float4 v;
+            v.x = F[0];
+            v.y = DX > 1 ? F[DX > 1 ? 1 : 0] : 0.f;
+            v.z = DX > 2 ? F[DX > 2 ? 2 : 0] : 0.f;
+            v.w = W;
+            *reinterpret_cast<float4*>(buf + j * PS) = v;
+        } else {
+            *reinterpret_cast<float4*>(buf + j * PS) = make_float4(F[0], F[1], F[2], F[3]);
+            *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(W, 0.f, 0.f, 0.f);
         }
     };
+    auto get_slot = [&](int tt, int j, float (&raw)[DX + 1]) {
+        const size_t tb = (size_t)tt * B + b;
+        const int jc = j < N ? j : N - 1;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) raw[d] = a.Fm[(tb * DX + d) * N + jc];
+        raw[DX] = a.logW[tb * N + jc];
+    };
+    auto stage_load = [&](int tt) {
+        st_t = tt;
+        st_l = a.lse[(size_t)tt * B + b];
+        if (tid < NP) get_slot(tt, tid, st);
+    };
     auto stage_store = [&](float* buf) {
-#pragma unroll
-        for (int r = 0; r < kMaxStage; ++r) {
-            const int j = tid + r * NTB;
-            if (j < NP) {
-                float F[DX];
-#pragma unroll
-                for (int d = 0; d < DX; ++d) F[d] = st[r][d] * rp[d];
-                const float W = j < N ? (st[r][DX] - st_l) * kLog2e : ninf;
-                if constexpr (DX <= 3) {
-                    float4 v;
-                    v.x = F[0];
-                    v.y = DX > 1 ? F[DX > 1 ? 1 : 0] : 0.f;
-                    v.z = DX > 2 ? F[DX > 2 ? 2 : 0] : 0.f;
-                    v.w = W;
-                    *reinterpret_cast<float4*>(buf + j * PS) = v;
-                } else {
-                    *reinterpret_cast<float4*>(buf + j * PS) = make_float4(F[0], F[1], F[2], F[3]);
-                    *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(W, 0.f, 0.f, 0.f);
-                }
-            }
+        if (tid < NP) put_slot(buf, tid, st, st_l);
+        for (int j = tid + NTB; j < NP; j += NTB) {
+            float raw[DX + 1];
+            get_slot(st_t, j, raw);
+            put_slot(buf, j, raw, st_l);
         }
     };
     // step t reads forward tile t-1; first tile needed is tile(0) at t = 1
@@ -256,9 +260,8 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
     StepIn cur_in, nxt_in;
     load_step(0, cur_in);
 
-    const int nq = NP >> 2;               // forward-tile entries per quad lane
-    const int nqh = (nq + HS - 1) / HS;   // ... per chain half
-    const int e0 = hpart * nqh, e1 = min(nq, (hpart + 1) * nqh);
+    const int nqh = (NP >> 2) / HS;       // forward-tile entries per quad lane and chain half (multiple of CH)
+    const int e0 = hpart * nqh, e1 = e0 + nqh;
 
     SEC_INIT(bsim_bwd)
     for (int t = 0; t < T; ++t) {
@@ -307,19 +310,20 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         if (!first) {
 #endif
             const float lam2 = cur_in.lam2;
-            float xq[4][DX], lq[4], dl[4], U[4][DX], V[4][DX];
+            // packed f32: sub-particles (0,1) and (2,3) of the quad share every v_pk_* instruction
+            float lq[4], dl[4];
             quad_bcast4(lam2, lq);
             quad_bcast4(dlam, dl);
+            const f2 lqa = f2{lq[0], lq[1]}, lqb = f2{lq[2], lq[3]};
+            const f2 dla = f2{dl[0], dl[1]}, dlb = f2{dl[2], dl[3]};
+            f2 xa[DX], xb[DX], Ua[DX], Ub[DX], Va[DX], Vb[DX];
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
                 float t4[4];
                 quad_bcast4(x[d] * rp[d], t4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xq[i][d] = t4[i];
-                    U[i][d] = 0.f;
-                    V[i][d] = 0.f;
-                }
+                xa[d] = f2{t4[0], t4[1]};
+                xb[d] = f2{t4[2], t4[3]};
+                Ua[d] = Ub[d] = Va[d] = Vb[d] = f2{0.f, 0.f};
             }
             float* ja = jacc + wave * NA * NP;
             // The walk over j is done in chunks of CH entries kept in registers; after each chunk the
@@ -330,31 +334,34 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                 float A[CH][NA];
 #pragma unroll
                 for (int i2 = 0; i2 < CH; ++i2) {
-                    const int e = c0 + i2;
-#pragma unroll
-                    for (int d = 0; d < NA; ++d) A[i2][d] = 0.f;
-                    if (e < e1) {
-                        const int j = e * 4 + q;
+                    {
+                        const int j = (c0 + i2) * 4 + q;
                         float F[DX], W;
                         read_slot<DX>(cur + j * PS, F, W);
+                        f2 ua[DX], ub[DX], la = f2{W, W}, lb = la;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            float u[DX], l = W;
+                        for (int d = 0; d < DX; ++d) {
+                            const f2 Fd = f2{F[d], F[d]};
+                            ua[d] = xa[d] - Fd;
+                            ub[d] = xb[d] - Fd;
+                            la = pk_fma(-ua[d], ua[d], la);
+                            lb = pk_fma(-ub[d], ub[d], lb);
+                        }
+                        la -= lqa;
+                        lb -= lqb;
+                        const f2 pa = f2{exp2_fast(la.x), exp2_fast(la.y)}, pb = f2{exp2_fast(lb.x), exp2_fast(lb.y)};
+                        const f2 ca = dla * pa, cb = dlb * pb;
+                        const f2 cs = ca + cb;
+                        A[i2][DX] = cs.x + cs.y;
 #pragma unroll
-                            for (int d = 0; d < DX; ++d) {
-                                u[d] = xq[i][d] - F[d];
-                                l = fmaf(-u[d], u[d], l);
-                            }
-                            const float p = exp2_fast(l - lq[i]);
-                            const float c = dl[i] * p;
-                            A[i2][DX] += c;
-#pragma unroll
-                            for (int d = 0; d < DX; ++d) {
-                                const float pu = p * u[d];
-                                U[i][d] += pu;
-                                V[i][d] = fmaf(pu, u[d], V[i][d]);
-                                A[i2][d] = fmaf(c, u[d], A[i2][d]);
-                            }
+                        for (int d = 0; d < DX; ++d) {
+                            const f2 pua = pa * ua[d], pub = pb * ub[d];
+                            Ua[d] += pua;
+                            Ub[d] += pub;
+                            Va[d] = pk_fma(pua, ua[d], Va[d]);
+                            Vb[d] = pk_fma(pub, ub[d], Vb[d]);
+                            const f2 ad = pk_fma(cb, ub[d], ca * ua[d]);
+                            A[i2][d] = ad.x + ad.y;
                         }
                     }
                 }
@@ -372,10 +379,8 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int e = c0 + ebase + r;
-                    if (e < e1) {
 #pragma unroll
-                        for (int d = 0; d < NA; ++d) ja[d * NP + e * 4 + q] = A[r][d];
-                    }
+                    for (int d = 0; d < NA; ++d) ja[d * NP + e * 4 + q] = A[r][d];
                 }
             }
             SEC(3);   // pair loop + butterflies
@@ -390,7 +395,8 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
-                    float u = U[i][d], v = V[i][d];
+                    float u = (i == 0) ? Ua[d].x : (i == 1) ? Ua[d].y : (i == 2) ? Ub[d].x : Ub[d].y;
+                    float v = (i == 0) ? Va[d].x : (i == 1) ? Va[d].y : (i == 2) ? Vb[d].x : Vb[d].y;
                     u = group_sum<4>(u);
                     v = group_sum<4>(v);
                     if (i == q) {
@@ -645,15 +651,18 @@ static int launch_bsim_bwd(const BsimBwdArgs& a, const BsimBwdOut& o, hipStream_
     using MG = MlpLds<DX, H, DY>;
     using AC = BAcc<DX, DY>;
     constexpr int PS = BTileSlot<DX>::kFloats;
-    const int NP = (a.N + 3) & ~3;
     int HS, NTB, cpb, nblk;
     bsim_geometry(a.B, a.N, M, H, DX, HS, NTB, cpb, nblk);
     const int nwv = NTB / 64;
+    // chunk of forward-tile entries reduced in registers per butterfly: 32 when a lane walks >= 32 entries
+    const int walk = ((a.N + 3) / 4 + HS - 1) / HS;
+    const int CHs = (HS == 2) ? 8 : (walk >= 32 ? 32 : 16);
+    const int pad = 4 * CHs * HS;
+    const int NP = ((a.N + pad - 1) / pad) * pad;     // as in the kernel
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nwv * (DX + 1) * NP +
                                         2 * cpb * DX + 16);
+    if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
-    // chunk of forward-tile entries reduced in registers per butterfly: 32 when a lane walks >= 32 entries
-    const int walk = (NP / 4 + HS - 1) / HS;
     if (HS == 2) {
         // chunks of 8 entries keep the half-split kernel at 251 VGPRs (two waves per SIMD, no scratch)
         if constexpr (2 * M <= 64 && (H / 2) % 4 == 0 && DX <= 2)
