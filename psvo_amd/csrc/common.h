@@ -89,50 +89,51 @@ struct MlpLds {
         for (int i = tid; i < ((DOUT + 3) & ~3); i += nthreads) w[kB2 + i] = i < DOUT ? p.b2[i] : 0.f;
     }
 
-    // four hidden units: h = relu(x W1[:, k:k+4] + b1[k:k+4]); out += h W2[k:k+4, :]
+    // Four hidden units with packed f32 math (units (k, k+1) and (k+2, k+3) share an instruction):
+    // h = relu(x W1[:, k:k+4] + b1[k:k+4]); acc[o] += h (*) W2[k:k+4, o] kept as two partial sums per output.
     __device__ __forceinline__ static void group4(const float* __restrict__ w, int k, const float (&x)[DIN],
-                                                  float (&out)[DOUT]) {
-        float4 h = *reinterpret_cast<const float4*>(w + kB1 + k);
+                                                  f2 (&acc)[DOUT]) {
+        const float4 b = *reinterpret_cast<const float4*>(w + kB1 + k);
+        f2 ha = f2{b.x, b.y}, hb = f2{b.z, b.w};
 #pragma unroll
         for (int i = 0; i < DIN; ++i) {
             const float4 wi = *reinterpret_cast<const float4*>(w + kW1 + i * H + k);
-            h.x = fmaf(x[i], wi.x, h.x);
-            h.y = fmaf(x[i], wi.y, h.y);
-            h.z = fmaf(x[i], wi.z, h.z);
-            h.w = fmaf(x[i], wi.w, h.w);
+            const f2 xi = f2{x[i], x[i]};
+            ha = pk_fma(xi, f2{wi.x, wi.y}, ha);
+            hb = pk_fma(xi, f2{wi.z, wi.w}, hb);
         }
-        h.x = fmaxf(h.x, 0.f);
-        h.y = fmaxf(h.y, 0.f);
-        h.z = fmaxf(h.z, 0.f);
-        h.w = fmaxf(h.w, 0.f);
+        const f2 zero = f2{0.f, 0.f};
+        ha = pk_max(ha, zero);
+        hb = pk_max(hb, zero);
 #pragma unroll
         for (int o = 0; o < DOUT; ++o) {
             const float4 wo = *reinterpret_cast<const float4*>(w + kW2 + o * H + k);
-            out[o] = fmaf(h.x, wo.x, out[o]);
-            out[o] = fmaf(h.y, wo.y, out[o]);
-            out[o] = fmaf(h.z, wo.z, out[o]);
-            out[o] = fmaf(h.w, wo.w, out[o]);
+            acc[o] = pk_fma(ha, f2{wo.x, wo.y}, acc[o]);
+            acc[o] = pk_fma(hb, f2{wo.z, wo.w}, acc[o]);
         }
     }
 
-    // out = relu(x W1 + b1) W2 + b2, hidden units accumulated in k order.
+    // out = relu(x W1 + b1) W2 + b2.
     // ROLLED = false: fully unrolled (the compiler may keep loop-invariant weights in VGPRs);
     // ROLLED = true : a real loop over groups of 8 hidden units (bounded register pressure).
     template <bool ROLLED = false>
     __device__ __forceinline__ static void eval(const float* __restrict__ w, const float (&x)[DIN],
                                                 float (&out)[DOUT]) {
+        f2 acc[DOUT];
 #pragma unroll
-        for (int o = 0; o < DOUT; ++o) out[o] = w[kB2 + o];
+        for (int o = 0; o < DOUT; ++o) acc[o] = f2{w[kB2 + o], 0.f};
         if constexpr (ROLLED && (H % 8 == 0) && (H > 8)) {
 #pragma unroll 1
             for (int k = 0; k < H; k += 8) {
-                group4(w, k, x, out);
-                group4(w, k + 4, x, out);
+                group4(w, k, x, acc);
+                group4(w, k + 4, x, acc);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < H; k += 4) group4(w, k, x, out);
+            for (int k = 0; k < H; k += 4) group4(w, k, x, acc);
         }
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) out[o] = acc[o].x + acc[o].y;
     }
 
     // Partial evaluation over the hidden units [part*H/S, (part+1)*H/S): S lanes share one MLP
@@ -143,10 +144,45 @@ struct MlpLds {
         constexpr int HP = H / S;
         static_assert(HP % 4 == 0, "hidden slice must be a multiple of 4");
         const float* wp = w + part * HP;  // shifts k in all three arrays (W1 rows, b1, W2T rows)
+        f2 acc[DOUT];
 #pragma unroll
-        for (int o = 0; o < DOUT; ++o) out[o] = part == 0 ? w[kB2 + o] : 0.f;
+        for (int o = 0; o < DOUT; ++o) acc[o] = f2{part == 0 ? w[kB2 + o] : 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < HP; k += 4) group4(wp, k, x, out);
+        for (int k = 0; k < HP; k += 4) group4(wp, k, x, acc);
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) out[o] = acc[o].x + acc[o].y;
+    }
+
+    // input gradient of four hidden units (recomputes their pre-activations; relu' = [pre > 0])
+    __device__ __forceinline__ static void bwd_group4(const float* __restrict__ w, int k, const float (&x)[DIN],
+                                                      const float (&dout)[DOUT], f2 (&dxa)[DIN]) {
+        const float4 b = *reinterpret_cast<const float4*>(w + kB1 + k);
+        f2 pa = f2{b.x, b.y}, pb = f2{b.z, b.w};
+        f2 wa[DIN], wb[DIN];
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) {
+            const float4 wi = *reinterpret_cast<const float4*>(w + kW1 + i * H + k);
+            wa[i] = f2{wi.x, wi.y};
+            wb[i] = f2{wi.z, wi.w};
+            const f2 xi = f2{x[i], x[i]};
+            pa = pk_fma(xi, wa[i], pa);
+            pb = pk_fma(xi, wb[i], pb);
+        }
+        f2 da = f2{0.f, 0.f}, db = da;
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) {
+            const float4 wo = *reinterpret_cast<const float4*>(w + kW2 + o * H + k);
+            const f2 go = f2{dout[o], dout[o]};
+            da = pk_fma(go, f2{wo.x, wo.y}, da);
+            db = pk_fma(go, f2{wo.z, wo.w}, db);
+        }
+        da = f2{pa.x > 0.f ? da.x : 0.f, pa.y > 0.f ? da.y : 0.f};
+        db = f2{pb.x > 0.f ? db.x : 0.f, pb.y > 0.f ? db.y : 0.f};
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) {
+            dxa[i] = pk_fma(da, wa[i], dxa[i]);
+            dxa[i] = pk_fma(db, wb[i], dxa[i]);
+        }
     }
 
     // dx += partial input gradient over the same hidden slice (caller sums dx over the S lanes)
@@ -155,87 +191,34 @@ struct MlpLds {
                                                           const float (&dout)[DOUT], float (&dx)[DIN]) {
         constexpr int HP = H / S;
         const float* wp = w + part * HP;
+        f2 dxa[DIN];
 #pragma unroll
-        for (int k = 0; k < HP; k += 4) {
-            float4 pre = *reinterpret_cast<const float4*>(wp + kB1 + k);
-            float4 wi[DIN];
+        for (int i = 0; i < DIN; ++i) dxa[i] = f2{dx[i], 0.f};
 #pragma unroll
-            for (int i = 0; i < DIN; ++i) {
-                wi[i] = *reinterpret_cast<const float4*>(wp + kW1 + i * H + k);
-                pre.x = fmaf(x[i], wi[i].x, pre.x);
-                pre.y = fmaf(x[i], wi[i].y, pre.y);
-                pre.z = fmaf(x[i], wi[i].z, pre.z);
-                pre.w = fmaf(x[i], wi[i].w, pre.w);
-            }
-            float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < HP; k += 4) bwd_group4(wp, k, x, dout, dxa);
 #pragma unroll
-            for (int o = 0; o < DOUT; ++o) {
-                const float4 wo = *reinterpret_cast<const float4*>(wp + kW2 + o * H + k);
-                dh.x = fmaf(dout[o], wo.x, dh.x);
-                dh.y = fmaf(dout[o], wo.y, dh.y);
-                dh.z = fmaf(dout[o], wo.z, dh.z);
-                dh.w = fmaf(dout[o], wo.w, dh.w);
-            }
-            dh.x = pre.x > 0.f ? dh.x : 0.f;
-            dh.y = pre.y > 0.f ? dh.y : 0.f;
-            dh.z = pre.z > 0.f ? dh.z : 0.f;
-            dh.w = pre.w > 0.f ? dh.w : 0.f;
-#pragma unroll
-            for (int i = 0; i < DIN; ++i) {
-                dx[i] = fmaf(dh.x, wi[i].x, dx[i]);
-                dx[i] = fmaf(dh.y, wi[i].y, dx[i]);
-                dx[i] = fmaf(dh.z, wi[i].z, dx[i]);
-                dx[i] = fmaf(dh.w, wi[i].w, dx[i]);
-            }
-        }
+        for (int i = 0; i < DIN; ++i) dx[i] = dxa[i].x + dxa[i].y;
     }
 
     // dx += (d out / d x)^T dout : recomputes the hidden pre-activations (nothing is stored)
     template <bool ROLLED = false>
     __device__ __forceinline__ static void bwd_input(const float* __restrict__ w, const float (&x)[DIN],
                                                      const float (&dout)[DOUT], float (&dx)[DIN]) {
-        auto g4 = [&](int k) {
-            float4 pre = *reinterpret_cast<const float4*>(w + kB1 + k);
-            float4 wi[DIN];
+        f2 dxa[DIN];
 #pragma unroll
-            for (int i = 0; i < DIN; ++i) {
-                wi[i] = *reinterpret_cast<const float4*>(w + kW1 + i * H + k);
-                pre.x = fmaf(x[i], wi[i].x, pre.x);
-                pre.y = fmaf(x[i], wi[i].y, pre.y);
-                pre.z = fmaf(x[i], wi[i].z, pre.z);
-                pre.w = fmaf(x[i], wi[i].w, pre.w);
-            }
-            float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int o = 0; o < DOUT; ++o) {
-                const float4 wo = *reinterpret_cast<const float4*>(w + kW2 + o * H + k);
-                dh.x = fmaf(dout[o], wo.x, dh.x);
-                dh.y = fmaf(dout[o], wo.y, dh.y);
-                dh.z = fmaf(dout[o], wo.z, dh.z);
-                dh.w = fmaf(dout[o], wo.w, dh.w);
-            }
-            dh.x = pre.x > 0.f ? dh.x : 0.f;
-            dh.y = pre.y > 0.f ? dh.y : 0.f;
-            dh.z = pre.z > 0.f ? dh.z : 0.f;
-            dh.w = pre.w > 0.f ? dh.w : 0.f;
-#pragma unroll
-            for (int i = 0; i < DIN; ++i) {
-                dx[i] = fmaf(dh.x, wi[i].x, dx[i]);
-                dx[i] = fmaf(dh.y, wi[i].y, dx[i]);
-                dx[i] = fmaf(dh.z, wi[i].z, dx[i]);
-                dx[i] = fmaf(dh.w, wi[i].w, dx[i]);
-            }
-        };
+        for (int i = 0; i < DIN; ++i) dxa[i] = f2{dx[i], 0.f};
         if constexpr (ROLLED && (H % 8 == 0) && (H > 8)) {
 #pragma unroll 1
             for (int k = 0; k < H; k += 8) {
-                g4(k);
-                g4(k + 4);
+                bwd_group4(w, k, x, dout, dxa);
+                bwd_group4(w, k + 4, x, dout, dxa);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < H; k += 4) g4(k);
+            for (int k = 0; k < H; k += 4) bwd_group4(w, k, x, dout, dxa);
         }
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) dx[i] = dxa[i].x + dxa[i].y;
     }
 };
 
