@@ -510,15 +510,15 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                     acc[AC::kSmm + d] += dmu[d] * mu[d];
                 }
             }
-            if constexpr (HS == 1) {
-                MQ::template bwd_input<kRolled>(wqi, xp, dmu1, dxp);
-            } else {
+            // MLP_q1inv's input is the same in all G lanes of the chain: spread its hidden units over kQS of them
+            {
+                constexpr int kQS = (H / 4 < G) ? H / 4 : G;
                 float dq[DX];
 #pragma unroll
                 for (int d = 0; d < DX; ++d) dq[d] = 0.f;
-                MQ::template bwd_input_part<HS>(wqi, hpart, xp, dmu1, dq);
+                MQ::template bwd_input_part<kQS>(wqi, (tid % G) & (kQS - 1), xp, dmu1, dq);
 #pragma unroll
-                for (int d = 0; d < DX; ++d) dxp[d] += dq[d] + xor_lane<M>(dq[d]);
+                for (int d = 0; d < DX; ++d) dxp[d] += group_sum<kQS>(dq[d]);
             }
         } else {
 #pragma unroll
@@ -537,32 +537,48 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         // ---- workgroup reductions: d bmu2[t] / d minit, d imean; flush d Fm / d logW partials ---------------------------
         if (m == 0 && h0) {
 #pragma unroll
-            for (int d = 0; d < DX; ++d) {
-                red[cl * DX + d] = valid ? outv[d] : 0.f;
-                red[(cpb + cl) * DX + d] = valid ? dim[d] : 0.f;
+            for (int d = 0; d < DX; ++d) {     // red[2*DX][cpb]: one row per summed quantity
+                red[d * cpb + cl] = valid ? outv[d] : 0.f;
+                red[(DX + d) * cpb + cl] = valid ? dim[d] : 0.f;
             }
         }
         __syncthreads();
-        if (tid < DX) {
-            float s0 = 0.f, s1 = 0.f;
-            for (int c = 0; c < cpb; ++c) {
-                s0 += red[c * DX + tid];
-                s1 += red[(cpb + c) * DX + tid];
+        if (tid < 2 * DX) {                    // lane r sums row r (independent LDS reads, four at a time)
+            const float* row = red + tid * cpb;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int c = 0;
+            for (; c + 4 <= cpb; c += 4) {
+                s0 += row[c];
+                s1 += row[c + 1];
+                s2 += row[c + 2];
+                s3 += row[c + 3];
             }
-            if (!last) a.dbmu2_part[(tb * nblk + blk) * DX + tid] = s0;
-            else {
-                a.dbmu2_part[(tb * nblk + blk) * DX + tid] = 0.f;
-                a.dminit_part[((size_t)b * nblk + blk) * DX + tid] = s0;
+            for (; c < cpb; ++c) s0 += row[c];
+            const float sum = (s0 + s1) + (s2 + s3);
+            if (tid < DX) {
+                if (!last) a.dbmu2_part[(tb * nblk + blk) * DX + tid] = sum;
+                else {
+                    a.dbmu2_part[(tb * nblk + blk) * DX + tid] = 0.f;
+                    a.dminit_part[((size_t)b * nblk + blk) * DX + tid] = sum;
+                }
+            } else if (first) {
+                a.dimean_part[((size_t)b * nblk + blk) * DX + (tid - DX)] = sum;
             }
-            if (first) a.dimean_part[((size_t)b * nblk + blk) * DX + tid] = s1;
         }
         if (!first) {
             // forward step t-1 receives d F (un-prescale: d F = d F' * rho, and the 1/(sigma kappa) factor)
             const size_t tbm = tb - B;
             for (int i = tid; i < NA * N; i += NTB) {
                 const int d = i / N, j = i - d * N;
-                float s = 0.f;
-                for (int w = 0; w < nwv; ++w) s += jacc[(w * NA + d) * NP + j];
+                const float* col = jacc + d * NP + j;
+                float s;
+                if (nwv == 4) {               // the usual 256-lane workgroup: four independent reads
+                    const float a0 = col[0], a1 = col[NA * NP], a2 = col[2 * NA * NP], a3 = col[3 * NA * NP];
+                    s = (a0 + a1) + (a2 + a3);
+                } else {
+                    s = 0.f;
+                    for (int w = 0; w < nwv; ++w) s += col[w * NA * NP];
+                }
                 if (d < DX) a.dFm_part[((tbm * nblk + blk) * DX + d) * N + j] = s * isf[d] / kappa;
                 else a.dlogW_part[(tbm * nblk + blk) * N + j] = s;
             }

@@ -234,12 +234,11 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
             }
         } else {
             float m1[DX], mu[DX];
-            if constexpr (HS == 1) {
-                MQ::template eval<kRolled>(wqi, xp, m1);
-            } else {
-                MQ::template eval_part<HS>(wqi, hpart, xp, m1);
+            {   // x_{t+1} is the same in all G lanes of the chain: spread MLP_q1inv's hidden units over kQS of them
+                constexpr int kQS = (H / 4 < G) ? H / 4 : G;
+                MQ::template eval_part<kQS>(wqi, (tid % G) & (kQS - 1), xp, m1);
 #pragma unroll
-                for (int d = 0; d < DX; ++d) m1[d] += xor_lane<M>(m1[d]);
+                for (int d = 0; d < DX; ++d) m1[d] = group_sum<kQS>(m1[d]);
             }
             if (a.mu1_all && valid && lead) {
 #pragma unroll
@@ -361,22 +360,23 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
             SEC(4);   // pair loop
             const float mx[4] = {mxa.x, mxa.y, mxb.x, mxb.y};
             const float sm[4] = {sma.x, sma.y, smb.x, smb.y};
-            // merge the four j-slices of the quad; lane q keeps sub-particle i == q
+            // merge the four j-slices of the quad (lane q keeps sub-particle i == q) and the chain's halves:
+            // common maximum first, then ONE rescale of the lane's own sum and plain adds
             float lm = ninf, ls = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float mm = mx[i], ss = sm[i];
-                lse2_merge(mm, ss, xor_lane<1>(mx[i]), xor_lane<1>(sm[i]));
-                const float m2 = xor_lane<2>(mm), s2 = xor_lane<2>(ss);
-                lse2_merge(mm, ss, m2, s2);
+                float gm = fmaxf(mx[i], xor_lane<1>(mx[i]));
+                gm = fmaxf(gm, xor_lane<2>(gm));
+                if constexpr (HS == 2) gm = fmaxf(gm, xor_lane<M>(gm));
+                const float base = (gm == ninf) ? 0.f : gm;
+                float sc = sm[i] * exp2_fast(mx[i] - base);    // (mx = -inf: sm = 0 and exp2(-inf) = 0)
+                sc += xor_lane<1>(sc);
+                sc += xor_lane<2>(sc);
+                if constexpr (HS == 2) sc += xor_lane<M>(sc);
                 if (i == q) {
-                    lm = mm;
-                    ls = ss;
+                    lm = gm;
+                    ls = sc;
                 }
-            }
-            if constexpr (HS == 2) {  // the other half of the chain walked the other forward particles
-                const float m2 = xor_lane<M>(lm), s2 = xor_lane<M>(ls);
-                lse2_merge(lm, ls, m2, s2);
             }
             const float lam2 = lm + log2_fast(ls);
             lam = fmaf(kLn2, lam2, kf);
