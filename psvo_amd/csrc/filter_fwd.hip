@@ -287,10 +287,278 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Four lanes per particle (N <= 256).  The filter runs ONE workgroup per sequence, so a step is a pure
+// latency chain; with lane = particle the two dependent MLP evaluations were > 40 % of it.  Here particle
+// n owns the quad of lanes 4n..4n+3: lane p evaluates hidden units [p*H/4, (p+1)*H/4) of every MLP (its
+// slice of the weights is loop-invariant and stays in registers) and the outputs are summed over the quad
+// with two DPP adds.  Everything else is computed redundantly in the four lanes; the multinomial search is a
+// two-round 16-ary search in which the quad reads 16 CDF pivots / 16 CDF entries as four float4 per round.
+// The per-sequence log-sum-exp and CDF use per-wave maxima and ONE barrier.
+// ---------------------------------------------------------------------------------------------
+template <int DX, int DY, int H, int MAXT>
+__global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    constexpr int P = 4;
+    constexpr bool kOpaque = false;   // (every instantiated shape keeps its weight slice in VGPRs without scratch)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = blockDim.x, nw = NT >> 6;
+    const int NPT = NT / P;                       // particle slots, a multiple of 16
+    const int b = blockIdx.x, B = a.B, T = a.T, N = a.N;
+    const int pn = tid >> 2, p = tid & 3;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);   // wave index as a scalar
+    const bool valid = pn < N;
+    const int n = valid ? pn : N - 1;
+
+    float* wq1 = smem;
+    float* wf = wq1 + MQ::kSize;
+    float* wg = wf + MQ::kSize;
+    float* cdf = wg + MG::kSize;   // [NPT]
+    float* piv = cdf + NPT;        // [16] cdf[16 i + 15], +inf beyond the last block
+    float* sx = piv + 16;          // [DX][NPT] staged X_t
+    float* sp = sx + DX * NPT;     // [DX][NPT] staged MLP_q1(X_t)
+    float* sf = sp + DX * NPT;     // [DX][NPT] staged MLP_f(X_t) (unused when bootstrap)
+    float* red = sf + DX * NPT;    // [2][16] per-wave (max, sum)
+
+    MQ::load(wq1, a.q1, tid, NT);
+    if (!a.bootstrap) MQ::load(wf, a.f, tid, NT);
+    MG::load(wg, a.g, tid, NT);
+    const float* wfm = a.bootstrap ? wq1 : wf;
+    if (tid < 16) piv[tid] = __builtin_huge_valf();
+
+    float sq1[DX], sq2[DX], sfv[DX], s0[DX], fs0[DX], isg[DY];
+    float lg = -DY * kHalfLog2Pi;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        sq1[d] = a.sig_q1[d];
+        sq2[d] = a.two_q ? a.sig_q2[d] : 1.f;
+        sfv[d] = a.bootstrap ? a.sig_q1[d] : a.sig_f[d];
+        s0[d] = a.sig0[d];
+        fs0[d] = a.fsig0[d];
+    }
+#pragma unroll
+    for (int e = 0; e < DY; ++e) {
+        const float s = a.sig_g[e];
+        isg[e] = 1.f / s;
+        lg -= logf(s);
+    }
+    const StepK<DX> K0 = make_stepk<DX>(s0, sq2, fs0, a.two_q != 0);
+    const StepK<DX> K1 = make_stepk<DX>(sq1, sq2, sfv, a.two_q != 0);
+    const float neg_logN = -logf((float)N);
+    const float ninf = -__builtin_huge_valf();
+
+    float mean1[DX], fmean[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        mean1[d] = a.m0[b * DX + d];
+        fmean[d] = a.fm0[b * DX + d];
+    }
+    float lnw = neg_logN;
+
+    float eps_c[DX], mu2_c[DX], obs_c[DY], u_c = 0.f;
+    int idx_c = 0;
+    auto load_inputs = [&](int t, float (&e)[DX], float (&m)[DX], float (&o)[DY], float& uu, int& ii) {
+        const size_t tb = (size_t)t * B + b;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            e[d] = a.eps[(tb * DX + d) * N + n];
+            m[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) o[k] = a.obs[tb * DY + k];
+        if (a.resample) {
+            if (a.idx_in) ii = a.idx_in[tb * N + n];
+            else uu = a.u[tb * N + n];
+        }
+    };
+    load_inputs(0, eps_c, mu2_c, obs_c, u_c, idx_c);
+    __syncthreads();  // weights visible
+
+    SEC_INIT(filter_fwd)
+    for (int t = 0; t < T; ++t) {
+        SEC(0);
+        const size_t tb = (size_t)t * B + b;
+        const StepK<DX> K = (t == 0) ? K0 : K1;
+        float eps_n[DX], mu2_n[DX], obs_n[DY], u_n = 0.f;
+        int idx_n = 0;
+        if (t + 1 < T) load_inputs(t + 1, eps_n, mu2_n, obs_n, u_n, idx_n);
+
+        SEC(1);
+        // ---- proposal (SVO.py:186-197), densities: the same in the four lanes of the particle --------
+        float mu[DX], x[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            mu[d] = a.two_q ? K.c[d] * fmaf(K.i1[d], mean1[d], K.i2[d] * mu2_c[d]) : mean1[d];
+            x[d] = fmaf(K.c[d], eps_c[d], mu[d]);
+        }
+        const float q_lp = diag_lp<DX>(x, mu, K.ic, K.lq);
+        const float f_lp = diag_lp<DX>(x, fmean, K.ifs, K.lf);
+
+        SEC(2);
+        // ---- the MLPs of the step, hidden units split over the quad ------------------------------------
+        // (the lane's weight slice is loop-invariant: the compiler keeps it in VGPRs when the budget allows;
+        //  otherwise an opaque LDS offset per step makes it re-read the slice instead of spilling it)
+        int zo = 0;
+        if (kOpaque) asm volatile("" : "+v"(zo));
+        float gm[DY], p1[DX], fm[DX];
+        MG::template eval_part<P>(wg + zo, p, x, gm);
+        MQ::template eval_part<P>(wq1 + zo, p, x, p1);
+        if (!a.bootstrap) MQ::template eval_part<P>(wfm + zo, p, x, fm);
+#pragma unroll
+        for (int k = 0; k < DY; ++k) gm[k] = group_sum<P>(gm[k]);
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            p1[d] = group_sum<P>(p1[d]);
+            fm[d] = a.bootstrap ? p1[d] : group_sum<P>(fm[d]);
+        }
+        const float g_lp = diag_lp<DY>(obs_c, gm, isg, lg);
+        float lw = f_lp + g_lp - q_lp + lnw;
+        if (!valid) lw = ninf;
+
+        if (valid) {   // history: one lane of the quad per array
+            if (p == 0) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.X[(tb * DX + d) * N + n] = x[d];
+                a.logW[tb * N + n] = lw;
+            } else if (p == 1) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.Fm[(tb * DX + d) * N + n] = fm[d];
+            } else if (p == 2 && a.P1) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.P1[(tb * DX + d) * N + n] = p1[d];
+            }
+        }
+
+        SEC(3);   // MLPs, quad sums, weight, history stores
+        // ---- log-sum-exp over particles + CDF: per-wave maxima, one barrier ------------------------------
+        const float wmx = wave_max(lw);
+        const float wbase = (wmx == ninf) ? 0.f : wmx;
+        const float w = (valid && p == 0) ? exp2_fast((lw - wbase) * kLog2e) : 0.f;
+        float sc = wave_incl_scan(w, lane);
+        if (lane == 63) {
+            red[wave] = wmx;
+            red[16 + wave] = sc;
+        }
+        if (a.resample) {   // stage the pre-resampling particle for the gather (one lane of the quad per array)
+            if (p == 1) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) sx[d * NPT + pn] = x[d];
+            } else if (p == 2) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) sp[d * NPT + pn] = p1[d];
+            } else if (p == 3 && !a.bootstrap) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) sf[d * NPT + pn] = fm[d];
+            }
+        }
+        SEC(4);   // wave max / scan, staging writes
+        __syncthreads();
+        SEC(5);   // barrier
+        // combine the (max, sum) pairs of the <= 16 waves in the lanes of a row: lane i holds wave i
+        const int li = lane & 15;
+        const float m_i = li < nw ? red[li] : ninf;
+        const float s_i = li < nw ? red[16 + li] : 0.f;
+        const float gmx = lane_bcast(group_max<16>(m_i), 0);
+        const float gbase = (gmx == ninf) ? 0.f : gmx;
+        const float v_i = s_i * exp2_fast((m_i - gbase) * kLog2e);        // (empty wave: 0 * exp2(-inf) = 0)
+        const float pre = group_incl_scan<16>(v_i, li);
+        const float total = lane_bcast(pre, nw - 1);
+        const float off = uwave > 0 ? lane_bcast(pre, max(uwave - 1, 0)) : 0.f;   // sum over the waves before this one
+        sc = fmaf(sc, exp2_fast((wbase - gbase) * kLog2e), off);
+        const float lse_t = fmaf(kLn2, log2_fast(total), gmx);
+        if (tid == 3) a.lse[tb] = lse_t;
+
+        SEC(6);   // cross-wave combination
+        if (a.resample) {
+            if (p == 0) {
+                cdf[pn] = sc;
+                if ((pn & 15) == 15) piv[pn >> 4] = sc;
+            }
+            __syncthreads();
+            SEC(7);   // cdf store + barrier
+            int idx;
+            if (a.idx_in) {
+                idx = idx_c;
+            } else {
+                // idx = #{k : cdf[k] <= u * total} (SVO.py:266-300 as defined in the oracle), two 16-ary rounds
+                const float target = u_c * total;
+                const float4 pv = *reinterpret_cast<const float4*>(piv + 4 * p);
+                float c1 = (pv.x <= target ? 1.f : 0.f) + (pv.y <= target ? 1.f : 0.f) +
+                           (pv.z <= target ? 1.f : 0.f) + (pv.w <= target ? 1.f : 0.f);
+                c1 = group_sum<P>(c1);
+                const int blk = min((int)c1, (NPT >> 4) - 1);
+                const float4 cv = *reinterpret_cast<const float4*>(cdf + 16 * blk + 4 * p);
+                float c2 = (cv.x <= target ? 1.f : 0.f) + (cv.y <= target ? 1.f : 0.f) +
+                           (cv.z <= target ? 1.f : 0.f) + (cv.w <= target ? 1.f : 0.f);
+                c2 = group_sum<P>(c2);
+                idx = min(16 * blk + (int)c2, N - 1);
+            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                x[d] = sx[d * NPT + idx];
+                mean1[d] = sp[d * NPT + idx];
+                fmean[d] = a.bootstrap ? mean1[d] : sf[d * NPT + idx];
+            }
+            if (valid) {
+                if (p == 3) a.idx_out[tb * N + n] = idx;
+                if (p == 0) {
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) a.Xanc[(tb * DX + d) * N + n] = x[d];
+                }
+            }
+            lnw = neg_logN;
+            SEC(8);   // search, gather, stores
+            __syncthreads();  // staged arrays / red[] are rewritten next step
+            SEC(9);   // barrier
+        } else {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                mean1[d] = p1[d];
+                fmean[d] = fm[d];
+            }
+            if (valid) {
+                if (p == 3) a.idx_out[tb * N + n] = n;
+                if (p == 0) {
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) a.Xanc[(tb * DX + d) * N + n] = x[d];
+                }
+            }
+            lnw = lw - lse_t;
+            __syncthreads();  // red[] reuse
+        }
+
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            eps_c[d] = eps_n[d];
+            mu2_c[d] = mu2_n[d];
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) obs_c[k] = obs_n[k];
+        u_c = u_n;
+        idx_c = idx_n;
+    }
+}
+
 template <int DX, int DY, int H>
 static int launch_filter(const FilterArgs& a, hipStream_t stream) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
+    // latency-bound regime (N <= 128: at most 512 lanes, 256 VGPRs each): four lanes per particle.  Only the
+    // shapes that compile without scratch use it; the rest keep one lane per particle.
+    constexpr bool kLppOk = (H % 16 == 0) && ((H <= 32 && DX <= 3) || H == 16);
+    if constexpr (kLppOk) {
+        if (a.N <= 128) {
+            const int NT4 = (4 * a.N + 63) & ~63;
+            const int NPT = NT4 / 4;
+            const size_t lds4 = sizeof(float) * (2 * MQ::kSize + MG::kSize + NPT + 16 + 3 * DX * NPT + 32);
+            clear_hip_error();
+            hipLaunchKernelGGL((filter_fwd_lpp_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT4), lds4, stream, a);
+            return launch_status();
+        }
+    }
     const int NT = (a.N + 63) & ~63;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + NT + 3 * DX * NT + 48);
     clear_hip_error();

@@ -197,7 +197,7 @@ def _pairs(model, P):
     return out
 
 
-def _check_grads(model, P, rtol=2e-3):
+def _grad_mismatches(model, P, rtol):
     bad = []
     for name, p, ref in _pairs(model, P):
         g = torch.zeros_like(ref) if p.grad is None else p.grad.detach().double().cpu()
@@ -206,6 +206,15 @@ def _check_grads(model, P, rtol=2e-3):
         err = (g - r).abs().max().item()
         if err > rtol * scale + 1e-6:
             bad.append((name, err, scale))
+    return bad
+
+
+def _check_grads(model, P, rtol=2e-3, rerun=None):
+    bad = _grad_mismatches(model, P, rtol)
+    if bad and rerun is not None:   # diagnostic: does a second HIP pass in the same process agree with the oracle?
+        rerun()
+        again = _grad_mismatches(model, P, rtol)
+        assert not bad, "gradient mismatch (name, max abs err, ref scale): %s; second pass: %s" % (bad, again)
     assert not bad, "gradient mismatch (name, max abs err, ref scale): %s" % bad
 
 
@@ -231,12 +240,15 @@ def test_filter_gradients(built_lib, case):
         nz.pop("u_b", None)
     if "anc_r" in nz:
         nz.pop("u_r", None)
-    model.zero_grad()
-    z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
-    z.backward()
-    torch.cuda.synchronize()
-    assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
-    _check_grads(model, P)
+    def hip_pass():
+        model.zero_grad()
+        z, _ = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
+        z.backward()
+        torch.cuda.synchronize()
+        return z
+    z = hip_pass()
+    assert abs(float(z.detach()) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+    _check_grads(model, P, rerun=hip_pass)
 
 
 def test_cross_lane_primitives(built_lib):
