@@ -154,7 +154,8 @@ int psvo_bsim_forward(const psvo_desc* desc,
  *            MLP_f(x~), dGt (T,B,Dy,N,M) w.r.t. MLP_g(x~), dmu1 (T,B,Dx,N) w.r.t. MLP_q1inv(bwX[t+1]);
  *            per-workgroup partials (nblk = psvo_bsim_blocks(B, N, M, H, Dx), to be summed over that axis):
  *            dFm_part (T,B,nblk,Dx,N), dlogW_part (T,B,nblk,N)  -> psvo_filter_backward,
- *            dbmu2_part (T,B,nblk,Dx), dminit_part (B,nblk,Dx), dimean_part (B,nblk,Dx);
+ *            per-chain rows (to be summed over N): dbmu2_rows (T,B,Dx,N), dminit_rows (B,Dx,N),
+ *            dimean_rows (B,Dx,N);
  *            scale gradients dsig_f, dsig_q1inv, dsig_bq2, dsig_init, disig (Dx), dsig_g (Dy).
  *  sacc_part: workspace, B * nblk * psvo_bsim_acc_size(Dx, Dy) floats.
  *  The gradient w.r.t. lse is identically zero (the normalised weights' gradients sum to zero).
@@ -172,8 +173,8 @@ int psvo_bsim_backward(const psvo_desc* desc,
                        const float* lam2_all, const float* om_all, const float* mu1_all,
                        const float* dscore,
                        float* xt, float* dFt, float* dGt, float* dmu1,
-                       float* dFm_part, float* dlogW_part, float* dbmu2_part, float* dminit_part,
-                       float* dimean_part,
+                       float* dFm_part, float* dlogW_part, float* dbmu2_rows, float* dminit_rows,
+                       float* dimean_rows,
                        float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
                        float* disig, float* sacc_part, void* stream);
 
@@ -250,9 +251,12 @@ int psvo_bsimwr_backward(const psvo_desc* desc,
  *              dF (T,B,Dx,N) w.r.t. MLP_f(X_t) (only when !bootstrap), dG (T,B,Dy,N) w.r.t. MLP_g(X_t);
  *            hoisted-input gradients dmu2 (T,B,Dx), dm0 (B,Dx), dfm0 (B,Dx);
  *            scale gradients dsig_q1, dsig_q2, dsig_f, dsig0, dfsig0 (Dx), dsig_g (Dy).
- *  sacc    : workspace, B * psvo_filter_acc_size(Dx, Dy) floats.
+ *  sacc    : workspace, psvo_filter_ws_floats(B, T, N, Dx, Dy) floats: B * psvo_filter_acc_size(Dx, Dy)
+ *            per-sequence sums followed by the (T,B,Dx,N) per-particle rows of d mu2, which a parallel
+ *            kernel sums over N after the time loop.
  * ------------------------------------------------------------------------------------------- */
 int psvo_filter_acc_size(int Dx, int Dy);
+long long psvo_filter_ws_floats(int B, int T, int N, int Dx, int Dy);
 int psvo_filter_backward(const psvo_desc* desc,
                          const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
                          const float* sig_q1, const float* sig_q2, const float* sig_f, const float* sig_g,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "psvo_last_hip_error": (ctypes.c_char_p, []),
     "psvo_filter_forward": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 20 + [_P]),
     "psvo_filter_acc_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "psvo_filter_ws_floats": (ctypes.c_longlong, [ctypes.c_int] * 5),
     "psvo_filter_backward": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 18 + [ctypes.c_int] + [_P] * 16),
     "psvo_mlp_wgrad_blocks": (ctypes.c_int, [ctypes.c_longlong]),
     "psvo_mlp_wgrad": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -171,8 +171,8 @@ class BsimFunction(torch.autograd.Function):
         gq = none4 if gb[2] is not None else ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
         dFm, dlogW = r["dFm"], r["dlogW"]
         return (None, None, None, None, None, dFm, dlogW, None) + tuple(gf) + tuple(gg) + tuple(gq) + (
-            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_part"].sum(2),
-            r["dminit_part"].sum(1), r["dsig_init"], r["dimean_part"].sum(1), r["disig"])
+            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_rows"].sum(-1),
+            r["dminit_rows"].sum(-1), r["dsig_init"], r["dimean_rows"].sum(-1), r["disig"])
 
 
 class BsimWRFunction(torch.autograd.Function):

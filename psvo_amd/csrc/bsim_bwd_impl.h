@@ -40,7 +40,7 @@ struct BsimBwdArgs {
     const float *lam2_all, *om_all, *mu1_all;
     const float* dscore;  // (B,N)
     float *xt, *dFt, *dGt, *dmu1;
-    float *dFm_part, *dlogW_part, *dbmu2_part, *dminit_part, *dimean_part, *sacc_part;
+    float *dFm_part, *dlogW_part, *dbmu2_rows, *dminit_rows, *dimean_rows, *sacc_part;
 };
 
 template <int DX, int DY>
@@ -535,36 +535,17 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 
         SEC(6);   // chain reductions, MLP_q1inv input gradient
         // ---- workgroup reductions: d bmu2[t] / d minit, d imean; flush d Fm / d logW partials ---------------------------
-        if (m == 0 && h0) {
+        // per-chain rows of d bmu2[t] / d minit / d imean: summed over the chains by the host afterwards (a
+        // workgroup sum here would add an LDS round trip to every step of the serial chain)
+        if (m == 0 && h0 && valid) {
 #pragma unroll
-            for (int d = 0; d < DX; ++d) {     // red[2*DX][cpb]: one row per summed quantity
-                red[d * cpb + cl] = valid ? outv[d] : 0.f;
-                red[(DX + d) * cpb + cl] = valid ? dim[d] : 0.f;
+            for (int d = 0; d < DX; ++d) {
+                a.dbmu2_rows[(tb * DX + d) * N + n] = last ? 0.f : outv[d];
+                if (last) a.dminit_rows[((size_t)b * DX + d) * N + n] = outv[d];
+                if (first) a.dimean_rows[((size_t)b * DX + d) * N + n] = dim[d];
             }
         }
         __syncthreads();
-        if (tid < 2 * DX) {                    // lane r sums row r (independent LDS reads, four at a time)
-            const float* row = red + tid * cpb;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int c = 0;
-            for (; c + 4 <= cpb; c += 4) {
-                s0 += row[c];
-                s1 += row[c + 1];
-                s2 += row[c + 2];
-                s3 += row[c + 3];
-            }
-            for (; c < cpb; ++c) s0 += row[c];
-            const float sum = (s0 + s1) + (s2 + s3);
-            if (tid < DX) {
-                if (!last) a.dbmu2_part[(tb * nblk + blk) * DX + tid] = sum;
-                else {
-                    a.dbmu2_part[(tb * nblk + blk) * DX + tid] = 0.f;
-                    a.dminit_part[((size_t)b * nblk + blk) * DX + tid] = sum;
-                }
-            } else if (first) {
-                a.dimean_part[((size_t)b * nblk + blk) * DX + (tid - DX)] = sum;
-            }
-        }
         if (!first) {
             // forward step t-1 receives d F (un-prescale: d F = d F' * rho, and the 1/(sigma kappa) factor)
             const size_t tbm = tb - B;

@@ -33,6 +33,7 @@ struct FilterBwdArgs {
     const float* dlogW_ext;  // (T,B,nparts,N) or null
     float *dP, *dF, *dG, *dmu2, *dm0, *dfm0;
     float* sacc;             // (B, NACC) per-sequence scalar accumulators (see finalize)
+    float* dm2_rows;         // (T,B,Dx,N) per-particle d mu2 rows, summed over N by row_sum_kernel afterwards
 };
 
 template <int DX, int DY>
@@ -319,8 +320,9 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
                 inc[AC::kSmm1 + d] += dmu * mean1[d];
                 inc[AC::kSmb + d] += dmu * m2[d];
                 inc[AC::kSmm + d] += dmu * mu[d];
-                const float s = block_sum(dm2, red, wave, lane, nw);
-                if (tid == 0) a.dmu2[tb * DX + d] = s;
+                // summed over the particles by a parallel kernel after the time loop: a block sum here would put
+                // a wave reduction, an LDS round trip and a barrier into every step of the serial chain
+                if (valid) a.dm2_rows[(tb * DX + d) * N + n] = dm2;
             } else {
                 dmean1[d] = dmu;
             }
@@ -429,6 +431,18 @@ __global__ void filter_bwd_finalize(const float* __restrict__ sacc, int B, int t
     }
 }
 
+// out[r] = sum_l in[r * L + l]: one wave per row
+__global__ void __launch_bounds__(256) row_sum_kernel(const float* __restrict__ in, long long rows, int L,
+                                                      float* __restrict__ out) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int l = lane; l < L; l += 64) s += in[r * L + l];
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+
 struct FilterBwdOut {
     float *dsig_q1, *dsig_q2, *dsig_f, *dsig_g, *dsig0, *dfsig0;
 };
@@ -444,6 +458,11 @@ static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipS
         hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, a);
     else
         hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT), lds, stream, a);
+    if (a.two_q) {
+        const long long rows = (long long)a.T * a.B * DX;
+        hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a.dm2_rows, rows,
+                           a.N, a.dmu2);
+    }
     hipLaunchKernelGGL((filter_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc, a.B, a.two_q, a.bootstrap,
                        a.sig_q1, a.sig_q2, a.sig0, o.dsig_q1, o.dsig_q2, o.dsig_f, o.dsig_g, o.dsig0, o.dfsig0);
     return launch_status();
@@ -471,6 +490,10 @@ static int fb_dispatch_dy(const FilterBwdArgs& a, const FilterBwdOut& o, int Dy,
 }  // namespace psvo
 
 extern "C" int psvo_filter_acc_size(int Dx, int Dy) { return 10 * Dx + Dy; }
+
+extern "C" long long psvo_filter_ws_floats(int B, int T, int N, int Dx, int Dy) {
+    return (long long)B * (10 * Dx + Dy) + (long long)T * B * Dx * N;
+}
 
 extern "C" int psvo_filter_backward(
     const psvo_desc* desc, const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g, const float* sig_q1,
@@ -501,6 +524,7 @@ extern "C" int psvo_filter_backward(
     a.X = X; a.Fm = Fm; a.P1 = P1; a.logW = logW; a.lse = lse; a.idx = idx;
     a.dlse = dlse; a.nparts = nparts; a.dFm_ext = dFm_ext; a.dlogW_ext = dlogW_ext;
     a.dP = dP; a.dF = dF; a.dG = dG; a.dmu2 = dmu2; a.dm0 = dm0; a.dfm0 = dfm0; a.sacc = sacc;
+    a.dm2_rows = sacc + (size_t)desc->B * psvo_filter_acc_size(desc->Dx, desc->Dy);
     FilterBwdOut o{dsig_q1, dsig_q2, dsig_f, dsig_g, dsig0, dfsig0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {

@@ -270,7 +270,7 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
     out = {"dP": z(T, B, Dx, N), "dF": None if desc.bootstrap else z(T, B, Dx, N), "dG": z(T, B, Dy, N),
            "dmu2": z(T, B, Dx) if desc.two_q else None, "dm0": z(B, Dx), "dfm0": z(B, Dx),
            "dsig_q1": z(Dx), "dsig_q2": z(Dx), "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig0": z(Dx), "dfsig0": z(Dx)}
-    sacc = z(B, lib.psvo_filter_acc_size(Dx, Dy))
+    sacc = z(lib.psvo_filter_ws_floats(B, T, N, Dx, Dy))
     nparts = 1 if (dFm is not None or dlogW is not None) else 0
     _mark("psvo_filter_backward", 0)
     st = lib.psvo_filter_backward(
@@ -311,8 +311,8 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
     nblk = lib.psvo_bsim_blocks(B, N, M, H, Dx)
     z = lambda *s: torch.empty(*s, device=dev)
     out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
-           "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N), "dbmu2_part": z(T, B, nblk, Dx),
-           "dminit_part": z(B, nblk, Dx), "dimean_part": z(B, nblk, Dx),
+           "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N), "dbmu2_rows": z(T, B, Dx, N),
+           "dminit_rows": z(B, Dx, N), "dimean_rows": z(B, Dx, N),
            "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx)}
     sacc = z(B, nblk, lib.psvo_bsim_acc_size(Dx, Dy))
     _mark("psvo_bsim_backward", 0)
@@ -323,8 +323,8 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
         _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(bs["bwX"]), _ptr(bs["sel"]),
         _ptr(bs["lam2"]), _ptr(bs["om"]), _ptr(bs["mu1"]), _ptr(dscore),
         _ptr(out["xt"]), _ptr(out["dFt"]), _ptr(out["dGt"]), _ptr(out["dmu1"]),
-        _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(out["dbmu2_part"]), _ptr(out["dminit_part"]),
-        _ptr(out["dimean_part"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
+        _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(out["dbmu2_rows"]), _ptr(out["dminit_rows"]),
+        _ptr(out["dimean_rows"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
         _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(sacc), _stream())
     _mark("psvo_bsim_backward", 1)
     _lib.check(st, "psvo_bsim_backward")
