@@ -301,7 +301,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic_Cstar.json")
         if args.workload == "C*" and os.path.exists(tp):
             key = {"psvo_bsim_backward": "bsim_bwd_kernel", "psvo_bsim_forward": "bsim_fwd_kernel",
-                   "psvo_filter_backward": "filter_bwd_kernel", "psvo_filter_forward": "filter_fwd_kernel"}[dominant]
+                   "psvo_filter_backward": "filter_bwd_kernel", "psvo_filter_forward": "filter_fwd"}[dominant]
             for k, v in json.load(open(tp))["kernels"].items():
                 if key in k:
                     traffic, traffic_src = v["hbm_MB_per_launch"] * 1e6, "profiles/r01_hbm_traffic_Cstar.json"
