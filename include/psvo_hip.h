@@ -22,8 +22,9 @@
  *     (the reference's own internal layout is (T, N, B, D), src/SMC/SVO.py:176-178; the
  *     host mirror permutes to the reference's (B, T, N, Dx) at the Python boundary).
  *   - per-particle MLPs have ONE hidden layer of width H (reference default `*_layers=[32]`,
- *     src/runner_flag.py:53-57); kernels are instantiated for Dx in {1..4}, Dy in {1,2,3},
- *     H in {8,16,32,64}.  Anything else returns PSVO_ERR_UNSUPPORTED (never a silent fallback).
+ *     src/runner_flag.py:53-57); kernels are instantiated for Dx in {2,3,4}, Dy in {1,2},
+ *     H in {16,32,64}, M in {4,8,16,32}; N <= 512 (filter, PSVOwR reverse pass), N <= 1024 (backward
+ *     simulation); any T, B <= 65535.  Anything else returns PSVO_ERR_UNSUPPORTED (never a silent fallback).
  */
 #ifndef PSVO_HIP_H
 #define PSVO_HIP_H
