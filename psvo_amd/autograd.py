@@ -48,6 +48,13 @@ def _cg(t):
     return None if t is None else t.contiguous()
 
 
+def _used_on(stream, tensors):
+    """tensors allocated from another stream's pool are about to be consumed on `stream`"""
+    for t in tensors:
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(stream)
+
+
 class FilterFunction(torch.autograd.Function):
     """psvo_filter_forward / psvo_filter_backward.
 
@@ -61,6 +68,9 @@ class FilterFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, desc, obs_TB, eps, u, idx_in, *t):
+        # missing upstream gradients stay None: a zero tensor materialised by the engine would be filled on the
+        # main stream AFTER the event the side-stream reverse pass waits for
+        ctx.set_materialize_grads(False)
         t = [_cf(v) for v in t]
         q1, f, g = tuple(t[0:4]), tuple(t[4:8]), tuple(t[8:12])
         sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0 = t[12:21]
@@ -75,6 +85,7 @@ class FilterFunction(torch.autograd.Function):
                                           obs_TB, eps, u, idx_in)
             ov.filter_done = torch.cuda.Event()
             ov.filter_done.record(ov.side)
+            _used_on(torch.cuda.current_stream(), filt.values())
         else:
             filt = ops.filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
                                       obs_TB, eps, u, idx_in)
@@ -104,6 +115,7 @@ class FilterFunction(torch.autograd.Function):
                                         obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
                                         gbufs=ctx.gbufs, before_wgrad=before_wgrad)
             main.wait_stream(side)
+            _used_on(main, r.values())
         else:
             r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
                                     obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),

@@ -11,10 +11,20 @@ import torch
 from . import _lib
 
 
-# Optional side stream for the native launches of one wrapper call.  Only the *launch* moves: output
-# buffers are still allocated from the current stream's pool, and every tensor handed to the kernel
-# is record_stream()'ed so the caching allocator does not recycle it before the side stream is done.
+# Optional side stream for the native launches of one wrapper call.  Buffers the wrapper allocates come from
+# the SIDE stream's pool: a block of the current stream's pool may have been freed by work that is still
+# queued there (the caching allocator recycles within a stream without waiting), and the side stream is not
+# ordered after that work.  Tensors that arrive from the current stream are record_stream()'ed when their
+# pointer is taken; whoever consumes the outputs on the current stream must order the streams (event /
+# wait_stream) and record_stream() them there (autograd.FilterFunction does).
 _LAUNCH_STREAM = None
+
+
+def _empty(*shape, **kw):
+    if _LAUNCH_STREAM is not None:
+        with torch.cuda.stream(_LAUNCH_STREAM):
+            return torch.empty(*shape, **kw)
+    return torch.empty(*shape, **kw)
 
 
 class launch_on(object):
@@ -121,10 +131,10 @@ def filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, 
     if desc.resample and u is None and idx_in is None:
         raise ValueError("resampling needs uniforms `u` or teacher-forced `idx_in`")
     out = {
-        "X": torch.empty(T, B, Dx, N, device=dev), "Xanc": torch.empty(T, B, Dx, N, device=dev),
-        "Fm": torch.empty(T, B, Dx, N, device=dev), "logW": torch.empty(T, B, N, device=dev),
-        "idx": torch.empty(T, B, N, device=dev, dtype=torch.int32), "lse": torch.empty(T, B, device=dev),
-        "P1": None if desc.bootstrap else torch.empty(T, B, Dx, N, device=dev),
+        "X": _empty(T, B, Dx, N, device=dev), "Xanc": _empty(T, B, Dx, N, device=dev),
+        "Fm": _empty(T, B, Dx, N, device=dev), "logW": _empty(T, B, N, device=dev),
+        "idx": _empty(T, B, N, device=dev, dtype=torch.int32), "lse": _empty(T, B, device=dev),
+        "P1": None if desc.bootstrap else _empty(T, B, Dx, N, device=dev),
     }
     _mark("psvo_filter_forward", 0)
     st = lib.psvo_filter_forward(
@@ -160,13 +170,13 @@ def bsim_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu
     if u_b is None and sel_in is None:
         raise ValueError("backward simulation needs uniforms `u_b` or teacher-forced `sel_in`")
     out = {
-        "bwX": torch.empty(T, B, Dx, N, device=dev), "flp": torch.empty(T, B, N, device=dev),
-        "glp": torch.empty(T, B, N, device=dev), "Omega": torch.empty(T, B, N, device=dev),
-        "sel": torch.empty(T, B, N, device=dev, dtype=torch.int32), "score": torch.empty(B, N, device=dev),
-        "lam2": torch.empty(T, B, N, M, device=dev) if save else None,
-        "om": torch.empty(T, B, N, M, device=dev) if save else None,
+        "bwX": _empty(T, B, Dx, N, device=dev), "flp": _empty(T, B, N, device=dev),
+        "glp": _empty(T, B, N, device=dev), "Omega": _empty(T, B, N, device=dev),
+        "sel": _empty(T, B, N, device=dev, dtype=torch.int32), "score": _empty(B, N, device=dev),
+        "lam2": _empty(T, B, N, M, device=dev) if save else None,
+        "om": _empty(T, B, N, M, device=dev) if save else None,
         # (row t = T-1 of mu1 is written as zeros by the kernel: there is no predecessor step)
-        "mu1": torch.empty(T, B, Dx, N, device=dev) if save else None,
+        "mu1": _empty(T, B, Dx, N, device=dev) if save else None,
     }
     _mark("psvo_bsim_forward", 0)
     st = lib.psvo_bsim_forward(
@@ -184,7 +194,7 @@ def bsim_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu
 def elbo_filter(desc, lse):
     lib = _lib.load()
     _chk(lse, (desc.T, desc.B), "lse")
-    out = torch.empty(desc.B, device=lse.device)
+    out = _empty(desc.B, device=lse.device)
     _lib.check(lib.psvo_elbo_filter(ctypes.byref(desc), _ptr(lse), _ptr(out), _stream()), "psvo_elbo_filter")
     return out
 
@@ -192,7 +202,7 @@ def elbo_filter(desc, lse):
 def elbo_bsim(desc, score):
     lib = _lib.load()
     _chk(score, (desc.B, desc.N), "score")
-    out = torch.empty(desc.B, device=score.device)
+    out = _empty(desc.B, device=score.device)
     _lib.check(lib.psvo_elbo_bsim(ctypes.byref(desc), _ptr(score), _ptr(out), _stream()), "psvo_elbo_bsim")
     return out
 
@@ -206,9 +216,9 @@ def bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=False):
     for nm, W, b in (("fw", W_fw, b_fw), ("bw", W_bw, b_bw)):
         _chk(W, (Din + Dh, 4 * Dh), "W_" + nm)
         _chk(b, (4 * Dh,), "b_" + nm)
-    out = torch.empty(B, T, 2 * Dh, device=x.device)
-    cs = torch.empty(2, B, T, Dh, device=x.device) if save else None
-    gates = torch.empty(2, B, T, 4 * Dh, device=x.device) if save else None
+    out = _empty(B, T, 2 * Dh, device=x.device)
+    cs = _empty(2, B, T, Dh, device=x.device) if save else None
+    gates = _empty(2, B, T, 4 * Dh, device=x.device) if save else None
     _mark("psvo_bilstm_forward", 0)
     st = lib.psvo_bilstm_forward(B, T, Din, Dh, _ptr(x), _ptr(W_fw), _ptr(b_fw), _ptr(W_bw), _ptr(b_bw),
                                  _ptr(out), _ptr(cs), _ptr(gates), _stream())
@@ -237,10 +247,10 @@ def mlp_wgrad(X, dOut, w, Din, H, Dout, grad=None, axis=2):
     ws = _mlp_struct(w, Din, H, Dout, "w")
     NP = Din * H + H + H * Dout + Dout
     nblk = lib.psvo_mlp_wgrad_blocks(S * L)
-    partial = torch.empty(nblk, NP, device=dev)
+    partial = _empty(nblk, NP, device=dev)
     acc = grad is not None
     if grad is None:
-        grad = torch.empty(NP, device=dev)
+        grad = _empty(NP, device=dev)
     _mark("psvo_mlp_wgrad", 0)
     st = lib.psvo_mlp_wgrad(S, L, Din, H, Dout, _ptr(X), _ptr(dOut), ctypes.byref(ws), _ptr(partial), _ptr(grad),
                             int(acc), _stream())
@@ -266,7 +276,7 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
     fs = None if desc.bootstrap else _mlp_struct(f, Dx, H, Dx, "f")
     gs = _mlp_struct(g, Dx, H, Dy, "g")
     _chk(dlse, (T, B), "dlse"); _chk(dFm, (T, B, Dx, N), "dFm"); _chk(dlogW, (T, B, N), "dlogW")
-    z = lambda *s: torch.empty(*s, device=dev)
+    z = lambda *s: _empty(*s, device=dev)
     out = {"dP": z(T, B, Dx, N), "dF": None if desc.bootstrap else z(T, B, Dx, N), "dG": z(T, B, Dy, N),
            "dmu2": z(T, B, Dx) if desc.two_q else None, "dm0": z(B, Dx), "dfm0": z(B, Dx),
            "dsig_q1": z(Dx), "dsig_q2": z(Dx), "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig0": z(Dx), "dfsig0": z(Dx)}
@@ -309,7 +319,7 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
             raise ValueError("bsim_backward needs bsim_forward(save=True) outputs (missing %s)" % k)
         _chk(bs[k], shp, k)
     nblk = lib.psvo_bsim_blocks(B, N, M, H, Dx)
-    z = lambda *s: torch.empty(*s, device=dev)
+    z = lambda *s: _empty(*s, device=dev)
     out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
            "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N), "dbmu2_rows": z(T, B, Dx, N),
            "dminit_rows": z(B, Dx, N), "dimean_rows": z(B, Dx, N),
@@ -362,8 +372,8 @@ def bsimwr_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, b
     _chk(u_r, (T, B, N), "u_r"); _chk(anc_in, (T, B, N), "anc_in", torch.int32)
     if (u_b is None and sel_in is None) or (u_r is None and anc_in is None):
         raise ValueError("PSVOwR needs uniforms (`u_b`, `u_r`) or teacher-forced indices (`sel_in`, `anc_in`)")
-    z = lambda *s: torch.empty(*s, device=dev)
-    zi = lambda *s: torch.empty(*s, device=dev, dtype=torch.int32)
+    z = lambda *s: _empty(*s, device=dev)
+    zi = lambda *s: _empty(*s, device=dev, dtype=torch.int32)
     out = {"bwX": z(T, B, Dx, N), "bwXanc": z(T, B, Dx, N), "bwW": z(T, B, N), "lseW": z(T, B),
            "sel": zi(T, B, N), "anc": zi(T, B, N),
            "lam2": z(T, B, N, M) if save else None, "om": z(T, B, N, M) if save else None,
@@ -396,7 +406,7 @@ def bsimwr_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, 
         if bs.get(k) is None:
             raise ValueError("bsimwr_backward needs bsimwr_forward(save=True) outputs (missing %s)" % k)
         _chk(bs[k], shp, k)
-    z = lambda *s: torch.empty(*s, device=dev)
+    z = lambda *s: _empty(*s, device=dev)
     out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
            "dFm": z(T, B, Dx, N), "dlogW": z(T, B, N), "dlse": z(T, B), "dbmu2": z(T, B, Dx),
            "dminit": z(B, Dx), "dimean": z(B, Dx),
@@ -434,7 +444,7 @@ def reduce_rows(part, nrows, stride, n, out, accumulate=False):
 
 def sigma_forward(raw, mins):
     lib = _lib.load()
-    sig = torch.empty_like(raw)
+    sig = _empty(raw.shape, device=raw.device, dtype=raw.dtype)
     _lib.check(lib.psvo_sigma_forward(_ptr(raw), _ptr(mins), _ptr(sig), raw.numel(), _stream()), "psvo_sigma_forward")
     return sig
 
@@ -454,9 +464,9 @@ def bilstm_backward(x, W_fw, W_bw, out, cs, gates, dout, gbufs=None):
     _chk(dout, (B, T, 2 * Dh), "dout"); _chk(out, (B, T, 2 * Dh), "out")
     _chk(cs, (2, B, T, Dh), "cs"); _chk(gates, (2, B, T, 4 * Dh), "gates")
     dev = x.device
-    dx_part = torch.empty(2, B, T, Din, device=dev)
-    dW_part = torch.empty(B, 2, Din + Dh, 4 * Dh, device=dev)
-    db_part = torch.empty(B, 2, 4 * Dh, device=dev)
+    dx_part = _empty(2, B, T, Din, device=dev)
+    dW_part = _empty(B, 2, Din + Dh, 4 * Dh, device=dev)
+    db_part = _empty(B, 2, 4 * Dh, device=dev)
     _mark("psvo_bilstm_backward", 0)
     st = lib.psvo_bilstm_backward(B, T, Din, Dh, _ptr(x), _ptr(W_fw), _ptr(W_bw), _ptr(out), _ptr(cs), _ptr(gates),
                                   _ptr(dout), _ptr(dx_part), _ptr(dW_part), _ptr(db_part), _stream())
