@@ -164,6 +164,26 @@ def stack_bidirectional_rnn(x_BTD, layers):
     return h
 
 
+def bidirectional_rnn(x_BTD, layers):
+    """tf.nn.bidirectional_dynamic_rnn over two MultiRNNCells (use_stack_rnn=False) -- src/SMC/SVO.py:342-346,
+    src/model.py:168-170: the layers are stacked inside each direction, the directions only meet at the end.
+    Returns (outputs_fw, outputs_bw), both (B, T, Dh_last)."""
+    fw = bw = x_BTD
+    for L in layers:
+        fw = run_rnn(fw, *L["fw"], reverse=False)
+        bw = run_rnn(bw, *L["bw"], reverse=True)
+    return fw, bw
+
+
+def static_rnn(x_BTD, layers):
+    """tf.nn.static_rnn(MultiRNNCell(y_smoother_f), ...) -- src/SMC/PSVO.py:208-212 (BSim_use_single_RNN):
+    the forward cells only, stacked; outputs (B, T, Dh_last)."""
+    h = x_BTD
+    for L in layers:
+        h = run_rnn(h, *L["fw"], reverse=False)
+    return h
+
+
 # --------------------------------------------------------------------------- #
 # L2: objectives
 # --------------------------------------------------------------------------- #
@@ -182,6 +202,7 @@ class OracleSVO:
         self.n_particles = flags["n_particles"]
         self.smooth_obs = smooth_obs
         self.resample_particles = resample_particles
+        self.use_stack_rnn = flags.get("use_stack_rnn", True)
 
     # -- SVO.py:313-331
     def preprocess_obs(self, obs):
@@ -195,14 +216,21 @@ class OracleSVO:
             preprocessed_X0 = preprocessed_X0 @ W + b
         return preprocessed_X0, preprocessed_obs
 
-    # -- SVO.py:333-369 (use_stack_rnn=True, X0_use_separate_RNN as flagged)
+    # -- SVO.py:333-369 (use_stack_rnn / X0_use_separate_RNN as flagged)
     def preprocess_obs_w_bRNN(self, obs):
         enc = self.params["bRNN"]
-        outputs = stack_bidirectional_rnn(obs, enc["y_smoother"])
-        preprocessed_obs = list(outputs.unbind(1))
-        if enc.get("X0_smoother") is not None:
-            outputs = stack_bidirectional_rnn(obs, enc["X0_smoother"])
-        preprocessed_X0 = torch.cat([outputs[:, -1], outputs[:, 0]], dim=-1)
+        if self.use_stack_rnn:
+            outputs = stack_bidirectional_rnn(obs, enc["y_smoother"])
+            preprocessed_obs = list(outputs.unbind(1))
+            if enc.get("X0_smoother") is not None:
+                outputs = stack_bidirectional_rnn(obs, enc["X0_smoother"])
+            outputs_fw = outputs_bw = outputs                            # SVO.py:360-361
+        else:
+            outputs_fw, outputs_bw = bidirectional_rnn(obs, enc["y_smoother"])
+            preprocessed_obs = list(torch.cat([outputs_fw, outputs_bw], dim=-1).unbind(1))
+            if enc.get("X0_smoother") is not None:
+                outputs_fw, outputs_bw = bidirectional_rnn(obs, enc["X0_smoother"])
+        preprocessed_X0 = torch.cat([outputs_fw[:, -1], outputs_bw[:, 0]], dim=-1)
         return preprocessed_X0, preprocessed_obs
 
     # -- SVO.py:182-232, diagonal branch
@@ -320,8 +348,12 @@ class OraclePSVO(OracleSVO):
         self.q1_inv = OracleMVN(params["q1_inv"])
         self.BSim_q_init = OracleMVN(params["BSim_q_init"])
         self.BSim_q2 = OracleMVN(params["BSim_q2"])
+        self.BSim_use_single_RNN = flags.get("BSim_use_single_RNN", False)
 
-    def BS_preprocess_obs(self, obs):            # PSVO.py:205-216 (BSim_use_single_RNN=False)
+    def BS_preprocess_obs(self, obs):            # PSVO.py:205-216
+        if self.BSim_use_single_RNN:
+            outputs = static_rnn(obs, self.params["bRNN"]["y_smoother"])
+            return None, list(outputs.unbind(1))     # (the final LSTM state the reference returns here is never read)
         return self.preprocess_obs_w_bRNN(obs)
 
     @staticmethod
@@ -458,9 +490,12 @@ def make_params(flags, seed=0, dtype=torch.float64, bias_scale=0.0):
     psvo = flags.get("objective") in ("PSVO", "PSVOwR")
     Dhs_y = flags.get("y_smoother_Dhs", [32])
     Dhs_x0 = flags.get("X0_smoother_Dhs", [32])
+    stacked = flags.get("use_stack_rnn", True)
+    single = psvo and flags.get("BSim_use_single_RNN", False)
     E = 2 * Dhs_y[-1] if smooth else Dy
     sep = flags.get("X0_use_separate_RNN", True)
-    E0 = 2 * 2 * (Dhs_x0[-1] if sep else Dhs_y[-1]) if smooth else Dy
+    # X0 feature: concat(outputs[-1], outputs[0]) of the (B,T,2Dh) stack outputs, or concat(fw[-1], bw[0])
+    E0 = (4 if stacked else 2) * (Dhs_x0[-1] if sep else Dhs_y[-1]) if smooth else Dy
     both = flags["use_bootstrap"] and flags["use_2_q"]
     q0_in = E0 if both else Dx
     si, sm = flags.get("sigma_init", 5.0), flags.get("sigma_min", 1.0)
@@ -477,15 +512,18 @@ def make_params(flags, seed=0, dtype=torch.float64, bias_scale=0.0):
         W = ((torch.rand(E0, Dx, generator=gen, dtype=torch.float64) * 2 - 1) * lim).to(dtype)
         P["X0_transformer"] = (W, torch.zeros(Dx, dtype=dtype))
     if smooth or psvo:
-        def stack(Dhs):
+        def stack(Dhs, chained):
+            # layer input: concat of both directions of the previous layer (stack_bidirectional), or the
+            # previous layer of the SAME direction (MultiRNNCell: use_stack_rnn=False / static_rnn)
             out, d = [], Dy
             for Dh in Dhs:
                 out.append({"fw": make_lstm(gen, d, Dh, dtype), "bw": make_lstm(gen, d, Dh, dtype)})
-                d = 2 * Dh
+                d = Dh if chained else 2 * Dh
             return out
-        P["bRNN"] = {"y_smoother": stack(Dhs_y), "X0_smoother": stack(Dhs_x0) if sep else None}
+        P["bRNN"] = {"y_smoother": stack(Dhs_y, (not stacked) or single),
+                     "X0_smoother": stack(Dhs_x0, not stacked) if sep else None}
     if psvo:
-        Eb = 2 * Dhs_y[-1]
+        Eb = Dhs_y[-1] if single else 2 * Dhs_y[-1]
         P["BSim_q_init"] = mk(Eb, Dx)
         P["q1_inv"] = mk(Dx, Dx)
         P["BSim_q2"] = mk(Eb, Dx)

@@ -87,6 +87,7 @@ class PSVO(SVO):
     def BS_preprocess_obs(self, obs):
         """PSVO.py:205-216."""
         if self.BSim_use_single_RNN:
-            raise NotImplementedError("BSim_use_single_RNN (unidirectional static_rnn) is not built yet")
+            # static_rnn over the forward cells only (PSVO.py:208-212); the final state it also returns is never read
+            return None, self.model.y_smoother(obs)
         # the X0 feature of this encoder pass is never read (PSVO.py:80): do not compute it
         return self.preprocess_obs_w_bRNN(obs, need_X0=False)

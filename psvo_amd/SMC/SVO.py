@@ -159,7 +159,11 @@ class SVO:
             return None, preprocessed_obs
         if self.X0_use_separate_RNN:
             outputs = X0_smoother(obs)
-        preprocessed_X0 = torch.cat([outputs[:, -1], outputs[:, 0]], dim=-1)
+        if self.use_stack_rnn:
+            preprocessed_X0 = torch.cat([outputs[:, -1], outputs[:, 0]], dim=-1)            # (B, 4Dh), SVO.py:360-367
+        else:
+            Dh = outputs.shape[-1] // 2                                                     # outputs = [fw | bw]
+            preprocessed_X0 = torch.cat([outputs[:, -1, :Dh], outputs[:, 0, Dh:]], dim=-1)  # (B, 2Dh)
         return preprocessed_X0, preprocessed_obs
 
     def n_step_prediction(self, n_steps, hidden, obs):

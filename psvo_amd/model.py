@@ -38,36 +38,84 @@ class LSTMBlockCellLayer(nn.Module):
 
 
 class StackBiRNN(nn.Module):
-    """tf.contrib.rnn.stack_bidirectional_dynamic_rnn over lists of LSTMBlockCells
-    (reference src/SMC/SVO.py:337-341): each layer consumes concat(fw, bw) of the previous."""
+    """The observation encoder over lists of LSTMBlockCells, in the reference's three wirings:
 
-    def __init__(self, Din, Dhs, name):
+    mode "stack": tf.contrib.rnn.stack_bidirectional_dynamic_rnn (src/SMC/SVO.py:337-341) -- each layer
+                  consumes concat(fw, bw) of the previous one; output (B, T, 2 Dh).
+    mode "multi": tf.nn.bidirectional_dynamic_rnn over two MultiRNNCells (use_stack_rnn=False,
+                  src/model.py:168-170, src/SMC/SVO.py:342-346) -- layers are chained inside each direction;
+                  output concat(fw, bw) (B, T, 2 Dh) of the last layer.
+    mode "uni":   tf.nn.static_rnn(MultiRNNCell(y_smoother_f)) (BSim_use_single_RNN, src/SMC/PSVO.py:208-212)
+                  -- forward cells only; output (B, T, Dh).
+    On the GPU every layer is ONE persistent launch (psvo_bilstm_forward / psvo_bilstm_backward).
+    """
+
+    def __init__(self, Din, Dhs, name, mode="stack"):
         super().__init__()
+        assert mode in ("stack", "multi", "uni")
+        self.mode = mode
         self.fw, self.bw = nn.ModuleList(), nn.ModuleList()
         d = Din
         for i, Dh in enumerate(Dhs):
             self.fw.append(LSTMBlockCellLayer(d, Dh, "{}_f_{}".format(name, i)))
-            self.bw.append(LSTMBlockCellLayer(d, Dh, "{}_b_{}".format(name, i)))
-            d = 2 * Dh
-        self.Dout = d
+            if mode != "uni":           # (TF builds a cell's variables on first use: the unused bw cells have none)
+                self.bw.append(LSTMBlockCellLayer(d, Dh, "{}_b_{}".format(name, i)))
+            d = 2 * Dh if mode == "stack" else Dh
+        self.Dh_last = Dhs[-1]
+        self.Dout = self.Dh_last if mode == "uni" else 2 * self.Dh_last
+
+    @staticmethod
+    def _gbufs(fw, bw):
+        gf, gb = fw.__dict__.get("_flat_grad"), bw.__dict__.get("_flat_grad")
+        return (gf, gb) if (gf is not None and gb is not None) else None
 
     def forward(self, x_BTD):
         h = x_BTD
         if h.is_cuda:
-            # one persistent HIP launch per layer and direction pair (psvo_bilstm_forward /
-            # psvo_bilstm_backward) instead of ~4 T launches of a per-step LSTM
             from .autograd import BiLSTMFunction
-            for fw, bw in zip(self.fw, self.bw):
-                gf, gb = fw.__dict__.get("_flat_grad"), bw.__dict__.get("_flat_grad")
-                gbufs = (gf, gb) if (gf is not None and gb is not None) else None
-                h = BiLSTMFunction.apply(gbufs, h, fw.kernel, fw.bias, bw.kernel, bw.bias)
+            if self.mode == "stack":
+                for fw, bw in zip(self.fw, self.bw):
+                    h = BiLSTMFunction.apply(self._gbufs(fw, bw), h, fw.kernel, fw.bias, bw.kernel, bw.bias)
+                return h
+            if self.mode == "uni":
+                # the bidirectional kernel with the forward cell in both slots; only the forward half is kept
+                for fw in self.fw:
+                    h = BiLSTMFunction.apply(None, h, fw.kernel, fw.bias, fw.kernel, fw.bias)[..., :fw.Dh]
+                return h
+            # "multi": layer i >= 1 reads only its own direction of the previous layer: embed its kernel into one
+            # that takes concat(fw, bw) with zero rows for the other direction (one launch per layer)
+            for i, (fw, bw) in enumerate(zip(self.fw, self.bw)):
+                if i == 0:
+                    h = BiLSTMFunction.apply(self._gbufs(fw, bw), h, fw.kernel, fw.bias, bw.kernel, bw.bias)
+                else:
+                    Dp = fw.Din
+                    z = fw.kernel.new_zeros(Dp, 4 * fw.Dh)
+                    kf = torch.cat([fw.kernel[:Dp], z, fw.kernel[Dp:]], dim=0)
+                    kb = torch.cat([z, bw.kernel[:Dp], bw.kernel[Dp:]], dim=0)
+                    h = BiLSTMFunction.apply(None, h, kf, fw.bias, kb, bw.bias)
             return h
         B = h.shape[0]
+
+        def run(cell, x, reverse):
+            z = x.new_zeros(1, B, cell.Dh)
+            if reverse:
+                x = x.flip(1)
+            y, _, _ = torch._VF.lstm(x, (z, z), list(cell.torch_weights()), True, 1, 0.0, self.training, False, True)
+            return y.flip(1) if reverse else y
+        if self.mode == "stack":
+            for fw, bw in zip(self.fw, self.bw):
+                flat = list(fw.torch_weights()) + list(bw.torch_weights())
+                z = h.new_zeros(2, B, fw.Dh)
+                h, _, _ = torch._VF.lstm(h, (z, z), flat, True, 1, 0.0, self.training, True, True)
+            return h
+        if self.mode == "uni":
+            for fw in self.fw:
+                h = run(fw, h, False)
+            return h
+        f = b = h
         for fw, bw in zip(self.fw, self.bw):
-            flat = list(fw.torch_weights()) + list(bw.torch_weights())
-            z = h.new_zeros(2, B, fw.Dh)
-            h, _, _ = torch._VF.lstm(h, (z, z), flat, True, 1, 0.0, self.training, True, True)
-        return h
+            f, b = run(fw, f, False), run(bw, b, True)
+        return torch.cat([f, b], dim=-1)
 
 
 class SSM(nn.Module):
@@ -100,8 +148,6 @@ class SSM(nn.Module):
 
         if self.poisson_emission:
             raise NotImplementedError("poisson_emission is outside the MI355X hot-path scope (SURVEY section 2 row 2)")
-        if not self.use_stack_rnn:
-            raise NotImplementedError("use_stack_rnn=False (tf.nn.bidirectional_dynamic_rnn) is not built yet")
 
         # placeholders of the reference (model.py:63-65) have no equivalent; kept as feed keys
         self.obs, self.hidden = "obs", "hidden"
@@ -115,7 +161,8 @@ class SSM(nn.Module):
         if self.SVO:
             E = 2 * self.y_smoother_Dhs[-1]
             Dh0 = self.X0_smoother_Dhs[-1] if self.X0_use_separate_RNN else self.y_smoother_Dhs[-1]
-            E0 = 4 * Dh0
+            # concat(outputs[-1], outputs[0]) of the stacked (B,T,2Dh) outputs, or concat(fw[-1], bw[0]) (SVO.py:360-367)
+            E0 = (4 if self.use_stack_rnn else 2) * Dh0
         else:
             E = E0 = self.Dy
         return E, E0
@@ -130,7 +177,8 @@ class SSM(nn.Module):
         self.q1_tran = mk(self.q1_layers, self.Dx, self.Dx, "q1_tran")
         self.q2_tran = mk(self.q2_layers, self.Dx, E, "q2_tran") if self.use_2_q else None
         if self.PSVO or self.PSVOwR:
-            Eb = 2 * self.y_smoother_Dhs[-1]
+            single = self.BSim_use_single_RNN                # features of static_rnn(y_smoother_f): (B, Dh)
+            Eb = (1 if single else 2) * self.y_smoother_Dhs[-1]
             self.BSim_q_init_tran = mk(self.q0_layers, self.Dx, Eb, "BSim_q_init_tran")
             self.q1_inv_tran = mk(self.q1_layers, self.Dx, self.Dx, "q1_inv_tran")
             self.BSim_q2_tran = mk(self.q2_layers, self.Dx, Eb, "BSim_q2_tran")
@@ -153,8 +201,10 @@ class SSM(nn.Module):
 
     def init_RNNs(self):                                     # model.py:162-192
         if self.SVO or self.PSVO or self.PSVOwR:
-            self.y_smoother = StackBiRNN(self.Dy, self.y_smoother_Dhs, "y_smoother")
-            self.X0_smoother = (StackBiRNN(self.Dy, self.X0_smoother_Dhs, "X0_smoother")
+            mode = "stack" if self.use_stack_rnn else "multi"
+            single = (self.PSVO or self.PSVOwR) and self.BSim_use_single_RNN
+            self.y_smoother = StackBiRNN(self.Dy, self.y_smoother_Dhs, "y_smoother", "uni" if single else mode)
+            self.X0_smoother = (StackBiRNN(self.Dy, self.X0_smoother_Dhs, "X0_smoother", mode)
                                 if self.X0_use_separate_RNN else None)
             self.bRNN = (self.y_smoother, self.X0_smoother)
         else:
@@ -204,8 +254,11 @@ class SSM(nn.Module):
             P["X0_transformer"] = (cv(self.X0_transformer_kernel), cv(self.X0_transformer_bias))
         if self.bRNN is not None:
             def stack(s):
-                return None if s is None else [{"fw": (cv(f.kernel), cv(f.bias)), "bw": (cv(b.kernel), cv(b.bias))}
-                                               for f, b in zip(s.fw, s.bw)]
+                if s is None:
+                    return None
+                bws = list(s.bw) + [None] * (len(s.fw) - len(s.bw))      # mode "uni": forward cells only
+                return [{"fw": (cv(f.kernel), cv(f.bias)), "bw": None if b is None else (cv(b.kernel), cv(b.bias))}
+                        for f, b in zip(s.fw, bws)]
             P["bRNN"] = {"y_smoother": stack(self.y_smoother), "X0_smoother": stack(self.X0_smoother)}
         if self.PSVO or self.PSVOwR:
             P["BSim_q_init"] = dist(self.Bsim_q_init_dist)
@@ -239,9 +292,10 @@ class SSM(nn.Module):
             for nm, s in (("y_smoother", self.y_smoother), ("X0_smoother", self.X0_smoother)):
                 if s is None:
                     continue
-                for L, f, b in zip(P["bRNN"][nm], s.fw, s.bw):
+                for i, (L, f) in enumerate(zip(P["bRNN"][nm], s.fw)):
                     put(f.kernel, L["fw"][0]); put(f.bias, L["fw"][1])
-                    put(b.kernel, L["bw"][0]); put(b.bias, L["bw"][1])
+                    if i < len(s.bw):
+                        put(s.bw[i].kernel, L["bw"][0]); put(s.bw[i].bias, L["bw"][1])
         if self.PSVO or self.PSVOwR:
             dist(self.Bsim_q_init_dist, P["BSim_q_init"]); dist(self.q1_inv_dist, P["q1_inv"])
             dist(self.BSim_q2_dist, P["BSim_q2"])

@@ -42,7 +42,18 @@ CASES = [
 ]
 
 
-def _setup(obj, B, T, N, M, Dx, Dy, H, bootstrap, two_q, seed=0):
+# encoder wirings other than the default stack_bidirectional_dynamic_rnn (reference src/model.py:168-178,
+# src/SMC/SVO.py:342-367, src/SMC/PSVO.py:208-212): (case, extra flags)
+ENCODER_CASES = [
+    (("SVO", 2, 7, 16, 4, 2, 1, 16, True, True), dict(use_stack_rnn=False, y_smoother_Dhs="8,16", X0_smoother_Dhs="16,8")),
+    (("SVO", 2, 6, 12, 4, 3, 1, 32, False, False), dict(use_stack_rnn=False, X0_use_separate_RNN=False)),
+    (("PSVO", 2, 6, 16, 8, 2, 1, 32, True, True), dict(BSim_use_single_RNN=True, y_smoother_Dhs="8,16")),
+    (("PSVO", 2, 6, 16, 8, 2, 1, 16, True, True), dict(use_stack_rnn=False, y_smoother_Dhs="16,8")),
+    (("PSVOwR", 2, 5, 12, 4, 2, 1, 16, True, True), dict(BSim_use_single_RNN=True)),
+]
+
+
+def _setup(obj, B, T, N, M, Dx, Dy, H, bootstrap, two_q, seed=0, **extra):
     from psvo_amd.model import SSM
     from psvo_amd.SMC.SVO import SVO
     from psvo_amd.SMC.PSVO import PSVO
@@ -51,9 +62,11 @@ def _setup(obj, B, T, N, M, Dx, Dy, H, bootstrap, two_q, seed=0):
     from psvo_amd.SMC.PSVOwR import PSVOwR
     cls = {"SVO": SVO, "PSVO": PSVO, "AESMC": AESMC, "IWAE": IWAE, "PSVOwR": PSVOwR}[obj]
     hs = str(H)
-    FLAGS = Hh.make_flags(obj, Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, batch_size=B, time=T,
-                          q0_layers=hs, q1_layers=hs, q2_layers=hs, f_layers=hs, g_layers=hs,
-                          y_smoother_Dhs="8", X0_smoother_Dhs="8", use_bootstrap=bootstrap, use_2_q=two_q)
+    kw = dict(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, batch_size=B, time=T,
+              q0_layers=hs, q1_layers=hs, q2_layers=hs, f_layers=hs, g_layers=hs,
+              y_smoother_Dhs="8", X0_smoother_Dhs="8", use_bootstrap=bootstrap, use_2_q=two_q)
+    kw.update(extra)
+    FLAGS = Hh.make_flags(obj, **kw)
     torch.manual_seed(seed)
     model = Hh.perturb_(SSM(FLAGS)).cuda()
     smc = cls(model, FLAGS)
@@ -189,9 +202,10 @@ def _pairs(model, P):
         for nm, s in (("y_smoother", model.y_smoother), ("X0_smoother", model.X0_smoother)):
             if s is None:
                 continue
-            for i, (f, b) in enumerate(zip(s.fw, s.bw)):
+            for i, f in enumerate(s.fw):
                 out.append(("%s.fw%d.W" % (nm, i), f.kernel, P["bRNN"][nm][i]["fw"][0]))
                 out.append(("%s.fw%d.b" % (nm, i), f.bias, P["bRNN"][nm][i]["fw"][1]))
+            for i, b in enumerate(s.bw):          # (none for the forward-only encoder of BSim_use_single_RNN)
                 out.append(("%s.bw%d.W" % (nm, i), b.kernel, P["bRNN"][nm][i]["bw"][0]))
                 out.append(("%s.bw%d.b" % (nm, i), b.bias, P["bRNN"][nm][i]["bw"][1]))
     return out
@@ -269,3 +283,36 @@ def test_cross_lane_primitives(built_lib):
     assert torch.allclose(out[6], torch.cumsum(x.double(), 0).float(), atol=1e-5)
     assert torch.allclose(out[7], x.double().sum().float().expand(64), atol=1e-5)
     assert torch.equal(out[8], x.max().expand(64))
+
+
+@pytest.mark.parametrize("case,extra", ENCODER_CASES, ids=lambda c: "-".join(map(str, c)) if isinstance(c, tuple) else
+                         ",".join("%s=%s" % kv for kv in c.items()))
+def test_encoder_variants(built_lib, case, extra):
+    """use_stack_rnn=False (two MultiRNNCells) and BSim_use_single_RNN (forward cells only): values, indices and
+    every gradient against the oracle."""
+    obj = case[0]
+    FLAGS, model, smc, obs, noise = _setup(*case, seed=7, **extra)
+    z_free, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
+    with torch.no_grad():
+        z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=Hh.noise_to_hip(noise, "cuda"))
+    assert abs(float(z) - float(z_free)) <= 1e-4 * abs(float(z_free))
+    assert torch.allclose(log["Xs"].double().cpu(), ref0["Xs"], atol=2e-4, rtol=1e-5)
+    teacher = {"idx_f": ref0["idx_f"]}
+    if obj in ("PSVO", "PSVOwR"):
+        teacher["idx_b"] = ref0["idx_b"]
+    if obj == "PSVOwR":
+        teacher["idx_r"] = ref0["idx_r"]
+    z_ref, P = _oracle_grads(model, FLAGS, obj, obs, noise, teacher)
+    nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
+    for k in ("u_f", "u_b", "u_r"):
+        nz.pop(k, None)
+
+    def hip_pass():
+        model.zero_grad()
+        zz, _ = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
+        zz.backward()
+        torch.cuda.synchronize()
+        return zz
+    zz = hip_pass()
+    assert abs(float(zz.detach()) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+    _check_grads(model, P, rerun=hip_pass)

@@ -74,6 +74,40 @@ def test_encoder_and_kstep_prediction_match_oracle_on_cpu():
     assert torch.allclose(smc.get_nextX(Xs[:, :, 0]).double(), o.get_nextX(Xs[:, :, 0].double()), atol=1e-5)
 
 
+def test_encoder_wirings_match_oracle_on_cpu():
+    """use_stack_rnn=False (MultiRNNCell per direction) and BSim_use_single_RNN (forward cells only): the host
+    encoder (CPU path) against the oracle's restatement, incl. the X0 feature widths"""
+    from psvo_amd.model import SSM
+    from psvo_amd.SMC.PSVO import PSVO
+    from psvo_amd.SMC.SVO import SVO
+    x = torch.randn(3, 9, 1)
+    # two MultiRNNCells
+    FLAGS = Hh.make_flags("SVO", Dx=2, Dy=1, time=9, batch_size=3, n_particles=4, use_stack_rnn=False,
+                          y_smoother_Dhs="6,4", X0_smoother_Dhs="5,3")
+    torch.manual_seed(3)
+    m = Hh.perturb_(SSM(FLAGS))
+    P = m.export_reference_layout(torch.float64)
+    fw, bw = O.bidirectional_rnn(x.double(), P["bRNN"]["y_smoother"])
+    assert torch.allclose(m.y_smoother(x).double(), torch.cat([fw, bw], -1), atol=1e-5)
+    X0, enc = SVO(m, FLAGS).preprocess_obs_w_bRNN(x)
+    X0_ref, enc_ref = O.OracleSVO(P, Hh.oracle_flags(FLAGS, "SVO")).preprocess_obs_w_bRNN(x.double())
+    assert X0.shape == (3, 2 * 3) and torch.allclose(X0.double(), X0_ref, atol=1e-5)
+    assert torch.allclose(enc.double(), torch.stack(enc_ref, 1), atol=1e-5)
+    assert m.q0_tran.kernels[0].shape[0] == 2 * 3          # q0 reads the (B, 2 Dh) feature directly (bootstrap and 2q)
+    # forward cells only
+    FLAGS = Hh.make_flags("PSVO", Dx=2, Dy=1, time=9, batch_size=3, n_particles=4, BSim_use_single_RNN=True,
+                          y_smoother_Dhs="6,4")
+    torch.manual_seed(4)
+    m = Hh.perturb_(SSM(FLAGS))
+    assert len(m.y_smoother.bw) == 0 and m.BSim_q2_tran.kernels[0].shape[0] == 4
+    P = m.export_reference_layout(torch.float64)
+    _, enc = PSVO(m, FLAGS).BS_preprocess_obs(x)
+    _, enc_ref = O.OraclePSVO(P, Hh.oracle_flags(FLAGS, "PSVO")).BS_preprocess_obs(x.double())
+    assert enc.shape == (3, 9, 4) and torch.allclose(enc.double(), torch.stack(enc_ref, 1), atol=1e-5)
+    m2 = SSM(FLAGS).load_reference_layout(P)
+    assert torch.equal(m2.y_smoother.fw[1].kernel, m.y_smoother.fw[1].kernel)
+
+
 def test_r_square_matches_oracle_restatement():
     from psvo_amd.trainer import trainer
     g = np.random.RandomState(0)
