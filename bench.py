@@ -180,6 +180,7 @@ def main():
 
     # HIP events around every native launch, on the stream they are launched on (torch's current stream)
     events = {}
+    marks = []                     # (name, phase, event) in issue order; ("step", 0, e) opens a step
     rec = {"on": False}
 
     def hook(name, phase, stream):
@@ -187,8 +188,16 @@ def main():
             e = torch.cuda.Event(enable_timing=True)
             e.record(stream)
             events.setdefault(name, []).append(e)
+            marks.append((name, phase, e))
+
+    def mark_step():
+        if rec["on"]:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            marks.append(("step", 0, e))
 
     def train_step():
+        mark_step()
         flat.zero_grad()
         z, _ = smc.get_log_ZSMC(obs, hidden)
         z.backward()
@@ -197,6 +206,7 @@ def main():
         return z
 
     def fwd_step():
+        mark_step()
         with torch.no_grad():
             z, _ = smc.get_log_ZSMC(obs, hidden)
         return z
@@ -287,6 +297,30 @@ def main():
         for name, evs in events.items():
             d = [evs[i].elapsed_time(evs[i + 1]) for i in range(0, len(evs) - 1, 2)]
             kms[name] = (sum(d) / ev_steps, len(d) / ev_steps)       # ms per step (all calls), calls per step
+        # where in the step each native kernel runs: [first start, last end] in ms after the step's first launch
+        timeline, t0e, per = {}, None, {}
+        for name, phase, e in marks + [("step", 0, None)]:
+            if name == "step":
+                if t0e is not None:
+                    for k, (a0, a1) in per.items():
+                        tl = timeline.setdefault(k, [0.0, 0.0])
+                        tl[0] += t0e.elapsed_time(a0) / ev_steps
+                        tl[1] += t0e.elapsed_time(a1) / ev_steps
+                t0e, per = e, {}
+            elif phase == 0:
+                per.setdefault(name, [e, e])
+            else:
+                per[name][1] = e
+        timeline = {k: [round(v[0], 3), round(v[1], 3)] for k, v in sorted(timeline.items(), key=lambda kv: kv[1][0])}
+        if os.environ.get("PSVO_BENCH_CALLS"):      # every native call of the last instrumented step, in issue order
+            last = max(i for i, m in enumerate(marks) if m[0] == "step")
+            t0c, calls, open_ = marks[last][2], [], {}
+            for name, phase, e in marks[last + 1:]:
+                if phase == 0:
+                    open_[name] = e
+                else:
+                    calls.append((name, round(t0c.elapsed_time(open_[name]), 3), round(t0c.elapsed_time(e), 3)))
+            print("calls:", calls, file=sys.stderr)
         flops, x_bsim = flop_model(Dx, Dy, N, M, H, Dy)
         cand = {k: v for k, v in kms.items() if k in flops}
         dominant = max(cand, key=lambda k: cand[k][0])
@@ -317,7 +351,8 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d (batch of sequences sharded)" % world,
                        "elbo": elbo, "forward_only_particle_steps_per_s": other,
                        "launch": "hipGraph replay" if use_graph else "eager",
-                       "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())}},
+                       "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())},
+                       "native_timeline_ms": timeline},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)",
                          "traffic_source": traffic_src,
