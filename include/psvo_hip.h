@@ -182,7 +182,8 @@ int psvo_bsim_backward(const psvo_desc* desc,
 /* ---------------------------------------------------------------------------------------------
  * PSVOwR: backward simulation with cross-chain resampling and a per-step ELBO.
  * Replaces PSVOwR.backward_simulation_w_resampling (reference src/SMC/PSVOwR.py:65-198), called from
- * PSVOwR.get_log_ZSMC (src/SMC/PSVOwR.py:38-62).  One persistent workgroup per sequence.
+ * PSVOwR.get_log_ZSMC (src/SMC/PSVOwR.py:38-62).  A sequence is owned by a cluster of
+ * psvo_bsimwr_blocks(B, N, M) persistent workgroups (cooperative launch) that meet at one barrier per step.
  *
  *  inputs  : as psvo_bsim_forward (the filter's Fm, logW, lse; the hoisted backward-proposal inputs),
  *            plus  u_r (T,B,N) uniforms of the cross-chain multinomial draw (or NULL with anc_in)
@@ -196,7 +197,11 @@ int psvo_bsim_backward(const psvo_desc* desc,
  *            sel_out, anc_out (T,B,N) drawn sub-particle / cross-chain ancestor indices
  *            lam2_all (T,B,N,M), om_all (T,B,N,M), mu1_all (T,B,Dx,N): optional saves for
  *            psvo_bsimwr_backward.
+ *  ws      : workspace, psvo_bsimwr_ws_floats(B, T, N) floats (the chains' selected normalised log-weights
+ *            and the per-sequence barrier counters; its last word is nonzero afterwards iff a barrier timed out).
  * ------------------------------------------------------------------------------------------- */
+int psvo_bsimwr_blocks(int B, int N, int M);
+long long psvo_bsimwr_ws_floats(int B, int T, int N);
 int psvo_bsimwr_forward(const psvo_desc* desc,
                         const float* Fm, const float* logW, const float* lse,
                         const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
@@ -208,18 +213,23 @@ int psvo_bsimwr_forward(const psvo_desc* desc,
                         float* bwX, float* bwXanc, float* bwW, float* lseW,
                         int32_t* sel_out, int32_t* anc_out,
                         float* lam2_all, float* om_all, float* mu1_all,
-                        void* stream);
+                        float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse mode of psvo_bsimwr_forward (TensorFlow autodiff of the loop above, src/trainer.py:115-118).
  *  inputs  : the forward call's inputs and outputs (all three saves required) and dlseW (T,B) =
  *            d loss / d lseW.
  *  outputs : rows for psvo_mlp_wgrad: xt, dFt (T,B,Dx,N,M), dGt (T,B,Dy,N,M), dmu1 (T,B,Dx,N) w.r.t.
- *            MLP_q1inv(bwXanc[t+1]);  dFm (T,B,Dx,N), dlogW (T,B,N), dlse (T,B) -> psvo_filter_backward
- *            (complete, no partial axis; here the gradient w.r.t. the filter's lse is NOT zero);
- *            dbmu2 (T,B,Dx), dminit (B,Dx), dimean (B,Dx); scale gradients as psvo_bsim_backward.
- *  sacc    : workspace, B * psvo_bsim_acc_size(Dx, Dy) floats.
+ *            MLP_q1inv(bwXanc[t+1]);  per-workgroup partials (K = psvo_bsimwr_blocks(B, N, M), to be summed
+ *            over that axis) dFm_part (T,B,K,Dx,N), dlogW_part (T,B,K,N), dlse_part (T,B,K) ->
+ *            psvo_filter_backward (here the gradient w.r.t. the filter's lse is NOT zero);
+ *            per-chain rows (to be summed over N) dbmu2_rows (T,B,Dx,N), dminit_rows (B,Dx,N),
+ *            dimean_rows (B,Dx,N); scale gradients as psvo_bsim_backward.
+ *  sacc    : workspace, B * K * psvo_bsim_acc_size(Dx, Dy) floats.
+ *  ws      : workspace, psvo_bsimwr_bwd_ws_floats(B, T, N, Dx) floats (d loss / d bwXanc exchanged between the
+ *            workgroups of a sequence, barrier counters; last word nonzero iff a barrier timed out).
  * ------------------------------------------------------------------------------------------- */
+long long psvo_bsimwr_bwd_ws_floats(int B, int T, int N, int Dx);
 int psvo_bsimwr_backward(const psvo_desc* desc,
                          const float* Fm, const float* logW, const float* lse,
                          const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
@@ -232,9 +242,10 @@ int psvo_bsimwr_backward(const psvo_desc* desc,
                          const float* lam2_all, const float* om_all, const float* mu1_all,
                          const float* dlseW,
                          float* xt, float* dFt, float* dGt, float* dmu1,
-                         float* dFm, float* dlogW, float* dlse, float* dbmu2, float* dminit, float* dimean,
+                         float* dFm_part, float* dlogW_part, float* dlse_part,
+                         float* dbmu2_rows, float* dminit_rows, float* dimean_rows,
                          float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
-                         float* disig, float* sacc, void* stream);
+                         float* disig, float* sacc, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse mode of psvo_filter_forward.  The reference obtains these gradients from TensorFlow

@@ -63,9 +63,10 @@ class PSVOwR(PSVO):
         desc = self._desc(M)
         gb = (self._gbuf(model.f_tran), self._gbuf(model.g_tran), self._gbuf(model.q1_inv_tran))
         desc._gbufs = gb if all(v is not None for v in gb) else None
-        lseW, bwXanc, bwX, bwW, sel, anc = BsimWRFunction.apply(
+        lseW, bwXanc, bwX, bwW, sel, anc, ws = BsimWRFunction.apply(
             desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, filt["Fm"], filt["logW"], filt["lse"],
             *model.f_tran.hip_params(), *model.g_tran.hip_params(), *model.q1_inv_tran.hip_params(),
             self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
             bmu2, minit, self._sigma(self.BSim_q_init), imean, isig)
-        return {"lseW": lseW, "bwXanc": bwXanc, "bwX": bwX, "bwW": bwW, "sel": sel, "anc": anc}
+        # ws[-1] (as int32) is nonzero iff a cluster barrier of the kernel timed out (checked by the tests)
+        return {"lseW": lseW, "bwXanc": bwXanc, "bwX": bwX, "bwW": bwW, "sel": sel, "anc": anc, "ws": ws}

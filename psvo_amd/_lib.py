@@ -48,8 +48,11 @@ SIGNATURES = {
     "psvo_bsim_blocks": (ctypes.c_int, [ctypes.c_int] * 5),
     "psvo_bsim_acc_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "psvo_bsim_backward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 34),
-    "psvo_bsimwr_forward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 24 + [_P]),
-    "psvo_bsimwr_backward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 38),
+    "psvo_bsimwr_blocks": (ctypes.c_int, [ctypes.c_int] * 3),
+    "psvo_bsimwr_ws_floats": (ctypes.c_longlong, [ctypes.c_int] * 3),
+    "psvo_bsimwr_forward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 25 + [_P]),
+    "psvo_bsimwr_bwd_ws_floats": (ctypes.c_longlong, [ctypes.c_int] * 4),
+    "psvo_bsimwr_backward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 39),
     "psvo_bilstm_forward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 8 + [_P]),
     "psvo_bilstm_backward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 10 + [_P]),
     "psvo_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,

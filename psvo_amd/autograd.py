@@ -211,8 +211,8 @@ class BsimWRFunction(torch.autograd.Function):
                                 isig, obs_TB, eps_b, u_b=u_b, u_r=u_r, sel_in=sel_in, anc_in=anc_in, save=need)
         ctx.desc, ctx.filt, ctx.bs = desc, filt, bs
         ctx.saved = (f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b)
-        ctx.mark_non_differentiable(bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"])
-        return bs["lseW"], bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"]
+        ctx.mark_non_differentiable(bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"], bs["ws"])
+        return bs["lseW"], bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"], bs["ws"]
 
     @staticmethod
     def backward(ctx, dlseW, *_):
@@ -237,8 +237,8 @@ class BsimWRFunction(torch.autograd.Function):
         gg = none4 if gb[1] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
         gq = none4 if gb[2] is not None else ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
         return (None,) * 7 + (r["dFm"], r["dlogW"], r["dlse"]) + tuple(gf) + tuple(gg) + tuple(gq) + (
-            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2"], r["dminit"], r["dsig_init"],
-            r["dimean"], r["disig"])
+            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_rows"].sum(-1),
+            r["dminit_rows"].sum(-1), r["dsig_init"], r["dimean_rows"].sum(-1), r["disig"])
 
 
 class BiLSTMFunction(torch.autograd.Function):

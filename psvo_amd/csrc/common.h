@@ -23,6 +23,15 @@ inline int launch_status() {
     return e == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
 }
 
+// PSVOwR: workgroups per sequence (cluster size) -- as many as keep every workgroup busy and the whole
+// cooperative grid resident (one workgroup per CU)
+static inline int wr_cluster(int B, int N, int M) {
+    int K = 8;
+    while (K > 1 && ((long long)B * K > 256 || N < 4 * K || (N + K - 1) / K * (K - 1) >= N)) K >>= 1;
+    (void)M;
+    return K;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Section timers (diagnostic builds only: tools/section_timers.py compiles one translation unit with
 // -DPSVO_SECTION_TIMERS into a separate library).  Lane 0 of workgroup (0,0) accumulates the shader-clock

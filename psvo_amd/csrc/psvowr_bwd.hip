@@ -1,6 +1,8 @@
 // Reverse mode of psvo_bsimwr_forward (PSVOwR, reference src/SMC/PSVOwR.py:65-198 under TensorFlow autodiff).
-// One persistent workgroup (512 lanes) per sequence walks t = 0 .. T-1 over the N*M (chain, sub-particle)
-// items in rounds.  With a = d loss / d bw_log_W[t, chain], pi_m = exp(omega_m), sel the drawn sub-particle and
+// As in the forward pass a sequence is owned by a cluster of K persistent workgroups (cooperative launch):
+// workgroup k walks t = 0 .. T-1 over the (chain, sub-particle) items of its own chains, publishes
+// d loss / d bwXanc_{t+1} of those chains to HBM and meets the others at one barrier per step; the next step
+// scatter-adds the published gradients of ALL chains into the parents it owns.  With a = d loss / d bw_log_W[t, chain], pi_m = exp(omega_m), sel the drawn sub-particle and
 //     bw_log_W = logsumexp_m(omega_raw) - phi_sel - log M,    omega_raw = Lambda + phi + g - q
 // the coefficients are
 //     d Lambda_m (d iota_m at t = 0) = d g_m = a pi_m,   d phi_m = a (pi_m - delta_{m,sel}),   d q_m = -a pi_m.
@@ -9,7 +11,8 @@
 // The cross-chain resampling (bwXanc_t[k] = bwX_t[anc_t[k]]) back-propagates as a scatter-add of
 // d bwXanc_t into the selected sub-particle of the parent chain (LDS float atomics, N*Dx per step).
 // The forward tile is recomputed (second pass) exactly as in bsim_bwd_impl.h: per-j partial sums are
-// reduce-scattered over the 16 quads of a wave with a butterfly and folded over waves through LDS.
+// reduce-scattered over the 16 quads of a wave with a butterfly, folded over waves through LDS and written as
+// per-workgroup partials; sums over chains (d bmu2, d minit, d imean) are left to the host as per-chain rows.
 #include "common.h"
 
 namespace psvo {
@@ -26,8 +29,40 @@ struct WrBwdArgs {
     const float *lam2_all, *om_all, *mu1_all;
     const float* dlseW;  // (T,B)
     float *xt, *dFt, *dGt, *dmu1;
-    float *dFm, *dlogW, *dlse, *dbmu2, *dminit, *dimean, *sacc;
+    float *dFm_part, *dlogW_part, *dlse_part;   // (T,B,K,Dx,N), (T,B,K,N), (T,B,K): per-workgroup partials
+    float *dbmu2_rows, *dminit_rows, *dimean_rows;   // (T,B,Dx,N), (B,Dx,N), (B,Dx,N): per-chain rows
+    float* sacc;                                 // (B,K,NACC)
+    float* dxg;                                  // (T,B,Dx,N) workspace: d loss / d bwXanc_t of every chain
+    unsigned* sync;                              // B barrier counters + 1 error flag
 };
+
+__device__ __forceinline__ float wb_ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// barrier over the K workgroups of a sequence (see psvowr_fwd.hip: bounded spin, error flag)
+__device__ __forceinline__ void wb_cluster_barrier(unsigned* cnt, unsigned* err, unsigned target, int K) {
+    __builtin_amdgcn_s_waitcnt(0);      // this lane's agent-scope stores have been acknowledged
+    __syncthreads();
+    if (K > 1) {
+        if (threadIdx.x == 0) {
+            // Everything the other workgroups read was written with agent-scope stores (write-through to the
+            // coherence point) and has completed (__syncthreads waits for this workgroup's stores), and it is read
+            // back with agent-scope loads: no L2 write-back / invalidate (__threadfence) is needed -- on this
+            // 8-XCD part that fence costs several microseconds per step.
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
 
 template <int DX, int DY>
 struct WAcc {   // same slots as BAcc in bsim_bwd_impl.h (shares bsim_bwd_finalize's algebra)
@@ -85,26 +120,26 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
     const int NTB = blockDim.x, nw = NTB >> 6;
     const int B = a.B, T = a.T, N = a.N;
     const int NP = (N + 3) & ~3;
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, kb = blockIdx.x, K = gridDim.x;
+    const int Nc = (N + K - 1) / K;                // chains per workgroup
+    const int c0 = kb * Nc, c1 = min(N, c0 + Nc);  // this workgroup's chains
     const int cpr = NTB / M;
-    const int rounds = (N + cpr - 1) / cpr;
+    const int rounds = (Nc + cpr - 1) / cpr;
     const int cl = tid / M, m = tid % M, q = m & 3;
+    unsigned* const bar = a.sync + b;
+    unsigned* const err = a.sync + B;
 
     float* wf = smem;
     float* wg = wf + MQ::kSize;
     float* wqi = wg + MG::kSize;
     float* tile = wqi + MQ::kSize;              // [2][NP][PS]
     float* jacc = tile + 2 * NP * PS;           // [nw][NA][NP] wave-private d F' / d W^ sums of the step
-    float* dxa = jacc + nw * NA * NP;           // [DX][N] d loss / d bwXanc_t (input of the step)
-    float* dxs = dxa + DX * N;                  // [DX][N] ... scattered to the parent chains' selected sub-particle
-    float* dxn = dxs + DX * N;                  // [DX][N] d loss / d bwXanc_{t+1} (output of the step)
-    float* cacc = dxn + DX * N;                 // [3][DX][N] per-chain d bmu2 / d minit / d imean contributions
-    float* red = cacc + 3 * DX * N;             // 64
+    float* dxs = jacc + nw * NA * NP;           // [DX][Nc] d loss / d (selected sub-particle) of the own chains
+    float* red = dxs + DX * Nc;                 // 64
 
     MQ::load(wf, a.f, tid, NTB);
     MG::load(wg, a.g, tid, NTB);
     MQ::load(wqi, a.q1inv, tid, NTB);
-    for (int i = tid; i < DX * N; i += NTB) dxa[i] = 0.f;
 
     const float kappa = sqrtf(0.5f * kLog2e);
     float isf[DX], rp[DX], isg[DY];
@@ -167,6 +202,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
     const bool owner = CH >= 16 || ((lane >> b3) & 1) == 0;
     __syncthreads();
 
+    unsigned nbar = 0;
     for (int t = 0; t < T; ++t) {
         const size_t tb = (size_t)t * B + b;
         const bool last = (t == T - 1), first = (t == 0);
@@ -174,14 +210,20 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
         float* nxt = tile + (t & 1) * NP * PS;               // tile(t), read at step t+1
         if (t + 1 < T && t >= 1) stage(t, nxt);
 
-        // ---- phase 0: scatter d bwXanc_t to the parent chains (bwXanc_t[k] = bwX_t[anc_t[k]]) -----------------
-        for (int i = tid; i < DX * N; i += NTB) dxs[i] = 0.f;
+        // ---- phase 0: scatter d bwXanc_t of ALL chains to the parents this workgroup owns
+        //      (bwXanc_t[k] = bwX_t[anc_t[k]]; d bwXanc_t was published by the owners during step t-1) -----------------
+        for (int i = tid; i < DX * Nc; i += NTB) dxs[i] = 0.f;
         for (int i = tid; i < nw * NA * NP; i += NTB) jacc[i] = 0.f;
         __syncthreads();
-        for (int k = tid; k < N; k += NTB) {
-            const int p = a.anc[tb * N + k];
+        if (t >= 1) {
+            for (int k = tid; k < N; k += NTB) {
+                const int p = a.anc[tb * N + k];
+                if (p >= c0 && p < c1) {
 #pragma unroll
-            for (int d = 0; d < DX; ++d) atomicAdd(&dxs[d * N + p], dxa[d * N + k]);
+                    for (int d = 0; d < DX; ++d)
+                        atomicAdd(&dxs[d * Nc + (p - c0)], wb_ld_agent(a.dxg + (tb * DX + d) * N + k));
+                }
+            }
         }
         __syncthreads();
 
@@ -195,9 +237,10 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
 
         // ---- phase 1: the (chain, sub-particle) items ----------------------------------------------------------
         for (int r = 0; r < rounds; ++r) {
-            const int n_raw = r * cpr + cl;
-            const bool valid = n_raw < N;
-            const int n = valid ? n_raw : N - 1;
+            const int n_raw = c0 + r * cpr + cl;
+            const bool valid = n_raw < c1 && (r * cpr + cl) < Nc;
+            const int n = valid ? n_raw : max(c1 - 1, 0);
+            const int nl = n - c0;
             const float aw = valid ? dlw * expf(a.bwW[tb * N + n] - lw) : 0.f;   // d loss / d bw_log_W[t, n]
             const int sel = a.sel[tb * N + n];
             float xp[DX], eps[DX], mu1[DX], mu[DX], x[DX];
@@ -223,7 +266,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
 
             float dxt[DX];
 #pragma unroll
-            for (int d = 0; d < DX; ++d) dxt[d] = issel * dxs[d * N + n];
+            for (int d = 0; d < DX; ++d) dxt[d] = issel * dxs[d * Nc + nl];
 
             if (!first) {
                 const float lam2 = a.lam2_all[(tb * N + n) * M + m];
@@ -395,30 +438,18 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
             if (lead) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
-                    dxn[d * N + n] = dxp[d];
-                    cacc[(0 * DX + d) * N + n] = outv[d];
-                    cacc[(1 * DX + d) * N + n] = dim[d];
+                    if (!last)     // d loss / d bwXanc_{t+1}[n], read by the whole cluster after the barrier
+                        __hip_atomic_store(a.dxg + ((tb + B) * DX + d) * N + n, dxp[d], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    a.dbmu2_rows[(tb * DX + d) * N + n] = last ? 0.f : outv[d];
+                    if (last) a.dminit_rows[((size_t)b * DX + d) * N + n] = outv[d];
+                    if (first) a.dimean_rows[((size_t)b * DX + d) * N + n] = dim[d];
                 }
             }
         }
         __syncthreads();
 
-        // ---- phase 2: per-sequence outputs of the step ----------------------------------------------------------------
-        for (int i = tid; i < DX * N; i += NTB) dxa[i] = dxn[i];     // becomes d bwXanc_{t+1}
-        for (int v = wave; v < 2 * DX; v += nw) {   // one wave sums vector v of cacc over the chains
-            float s = 0.f;
-            for (int i = lane; i < N; i += 64) s += cacc[v * N + i];
-            s = wave_sum(s);
-            if (lane == 0) {
-                const int which = v / DX, d = v % DX;
-                if (which == 0) {
-                    a.dbmu2[tb * DX + d] = last ? 0.f : s;
-                    if (last) a.dminit[(size_t)b * DX + d] = s;
-                } else if (first) {
-                    a.dimean[(size_t)b * DX + d] = s;
-                }
-            }
-        }
+        // ---- phase 2: this workgroup's partial of d Fm[t-1] / d logW[t-1] / d lse[t-1] -----------------------------------
         if (!first) {
             const size_t tbm = tb - B;
             float wsum = 0.f;
@@ -426,9 +457,9 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                 const int d = i / N, j = i - d * N;
                 float s = 0.f;
                 for (int w = 0; w < nw; ++w) s += jacc[(w * NA + d) * NP + j];
-                if (d < DX) a.dFm[(tbm * DX + d) * N + j] = s * isf[d] / kappa;
+                if (d < DX) a.dFm_part[((tbm * K + kb) * DX + d) * N + j] = s * isf[d] / kappa;
                 else {
-                    a.dlogW[tbm * N + j] = s;
+                    a.dlogW_part[(tbm * K + kb) * N + j] = s;
                     wsum += s;
                 }
             }
@@ -439,18 +470,19 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
             if (tid == 0) {
                 float s = 0.f;
                 for (int w = 0; w < nw; ++w) s += red[w];
-                a.dlse[tbm] = -s;
+                a.dlse_part[tbm * K + kb] = -s;
             }
         }
         if (last) {
             for (int i = tid; i < NA * N; i += NTB) {
                 const int d = i / N, j = i - d * N;
-                if (d < DX) a.dFm[(tb * DX + d) * N + j] = 0.f;
-                else a.dlogW[tb * N + j] = 0.f;
+                if (d < DX) a.dFm_part[((tb * K + kb) * DX + d) * N + j] = 0.f;
+                else a.dlogW_part[(tb * K + kb) * N + j] = 0.f;
             }
-            if (tid == 0) a.dlse[tb] = 0.f;
+            if (tid == 0) a.dlse_part[tb * K + kb] = 0.f;
         }
-        __syncthreads();
+        if (!last) wb_cluster_barrier(bar, err, (unsigned)K * (++nbar), K);   // d bwXanc_{t+1} of every chain is published
+        else __syncthreads();
     }
 
     for (int i = 0; i < AC::kN; ++i) {
@@ -463,7 +495,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
         if (tid == 0) {
             float s = 0.f;
             for (int w = 0; w < nw; ++w) s += red[w];
-            a.sacc[(size_t)b * AC::kN + i] = s;
+            a.sacc[((size_t)b * K + kb) * AC::kN + i] = s;
         }
         __syncthreads();
     }
@@ -509,17 +541,28 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
     using MG = MlpLds<DX, H, DY>;
     constexpr int PS = WbSlot<DX>::kFloats;
     const int NP = (a.N + 3) & ~3;
-    long long items = (long long)a.N * M;
+    const int K = wr_cluster(a.B, a.N, M);
+    const int Nc = (a.N + K - 1) / K;
+    long long items = (long long)Nc * M;
     int NTB = (int)(((items + 63) / 64) * 64);
     if (NTB > 512) NTB = 512;
     const int nw = NTB / 64;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nw * (DX + 1) * NP +
-                                        6 * DX * (size_t)a.N + 64);
+                                        (size_t)DX * Nc + 64);
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
-    hipLaunchKernelGGL((psvowr_bwd_kernel<DX, DY, H, M>), dim3(a.B), dim3(NTB), lds, stream, a);
-    hipLaunchKernelGGL((psvowr_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc, a.B, a.sig_q1inv, a.sig_bq2,
-                       o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
+    if (hipMemsetAsync(a.sync, 0, sizeof(unsigned) * (a.B + 1), stream) != hipSuccess) return launch_status();
+    WrBwdArgs args = a;
+    void* kargs[] = {(void*)&args};
+    const hipError_t e = hipLaunchCooperativeKernel((const void*)psvowr_bwd_kernel<DX, DY, H, M>, dim3(K, a.B), dim3(NTB),
+                                                    kargs, lds, stream);
+    if (e != hipSuccess) {
+        g_last_hip_error = e;
+        (void)hipGetLastError();
+        return PSVO_ERR_HIP;
+    }
+    hipLaunchKernelGGL((psvowr_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc, a.B * K, a.sig_q1inv,
+                       a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
     return launch_status();
 }
 
@@ -555,23 +598,28 @@ static int wb_dispatch_dy(const WrBwdArgs& a, const WrBwdOut& o, int Dy, int H, 
 
 }  // namespace psvo
 
+extern "C" long long psvo_bsimwr_bwd_ws_floats(int B, int T, int N, int Dx) {
+    return (long long)T * B * Dx * N + B + 1;
+}
+
 extern "C" int psvo_bsimwr_backward(
     const psvo_desc* desc, const float* Fm, const float* logW, const float* lse, const psvo_mlp* f, const psvo_mlp* g,
     const psvo_mlp* q1_inv, const float* sig_f, const float* sig_g, const float* sig_q1inv, const float* sig_bq2,
     const float* bmu2, const float* minit, const float* sig_init, const float* imean, const float* isig,
     const float* obs, const float* eps_b, const float* bwXanc, const float* bwW, const float* lseW, const int32_t* sel,
     const int32_t* anc, const float* lam2_all, const float* om_all, const float* mu1_all, const float* dlseW, float* xt,
-    float* dFt, float* dGt, float* dmu1, float* dFm, float* dlogW, float* dlse, float* dbmu2, float* dminit,
-    float* dimean, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init, float* disig,
-    float* sacc, void* stream) {
+    float* dFt, float* dGt, float* dmu1, float* dFm_part, float* dlogW_part, float* dlse_part, float* dbmu2_rows,
+    float* dminit_rows, float* dimean_rows, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2,
+    float* dsig_init, float* disig, float* sacc, float* ws, void* stream) {
     using namespace psvo;
     if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 || !bmu2 ||
         !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwXanc || !bwW || !lseW || !sel || !anc ||
-        !lam2_all || !om_all || !mu1_all || !dlseW || !xt || !dFt || !dGt || !dmu1 || !dFm || !dlogW || !dlse ||
-        !dbmu2 || !dminit || !dimean || !dsig_f || !dsig_g || !dsig_q1inv || !dsig_bq2 || !dsig_init || !disig || !sacc)
+        !lam2_all || !om_all || !mu1_all || !dlseW || !xt || !dFt || !dGt || !dmu1 || !dFm_part || !dlogW_part ||
+        !dlse_part || !dbmu2_rows || !dminit_rows || !dimean_rows || !dsig_f || !dsig_g || !dsig_q1inv || !dsig_bq2 ||
+        !dsig_init || !disig || !sacc || !ws)
         return PSVO_ERR_INVALID;
     if (desc->B <= 0 || desc->T < 2 || desc->N <= 0 || desc->M <= 0) return PSVO_ERR_INVALID;
-    if (desc->N > 512 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
+    if (desc->N > 1024 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
     WrBwdArgs a;
     a.B = desc->B; a.T = desc->T; a.N = desc->N;
     a.f = *f; a.g = *g; a.q1inv = *q1_inv;
@@ -580,8 +628,11 @@ extern "C" int psvo_bsimwr_backward(
     a.bmu2 = bmu2; a.minit = minit; a.sig_init = sig_init; a.imean = imean; a.isig = isig;
     a.obs = obs; a.eps_b = eps_b; a.bwXanc = bwXanc; a.bwW = bwW; a.lseW = lseW; a.sel = sel; a.anc = anc;
     a.lam2_all = lam2_all; a.om_all = om_all; a.mu1_all = mu1_all; a.dlseW = dlseW;
-    a.xt = xt; a.dFt = dFt; a.dGt = dGt; a.dmu1 = dmu1; a.dFm = dFm; a.dlogW = dlogW; a.dlse = dlse;
-    a.dbmu2 = dbmu2; a.dminit = dminit; a.dimean = dimean; a.sacc = sacc;
+    a.xt = xt; a.dFt = dFt; a.dGt = dGt; a.dmu1 = dmu1;
+    a.dFm_part = dFm_part; a.dlogW_part = dlogW_part; a.dlse_part = dlse_part;
+    a.dbmu2_rows = dbmu2_rows; a.dminit_rows = dminit_rows; a.dimean_rows = dimean_rows; a.sacc = sacc;
+    a.dxg = ws;
+    a.sync = reinterpret_cast<unsigned*>(ws + (size_t)desc->T * desc->B * desc->Dx * desc->N);
     WrBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {

@@ -1,10 +1,14 @@
 // PSVOwR backward simulation: PSVO's backward simulation with an additional multinomial resampling
 // ACROSS the chains of a sequence after every step and a per-step ELBO (reference
-// src/SMC/PSVOwR.py:65-198).  The cross-chain draw couples all N chains of a sequence once per step, so
-// this variant runs ONE persistent workgroup per sequence (up to 1024 lanes) that walks the N*M
-// (chain, sub-particle) items in rounds; chain state lives in LDS between steps.  The per-item work
-// (proposal, MLP_f / MLP_g, quad-blocked pass over the LDS-staged forward tile, normalisation and draw
-// over the M sub-particles) is the same arithmetic as psvo_bsim_forward.
+// src/SMC/PSVOwR.py:65-198).
+//
+// The cross-chain draw couples all N chains of a sequence once per step.  A sequence is therefore owned by a
+// CLUSTER of K persistent workgroups (K = 1, 2, 4 or 8; cooperative launch, so that all of them are resident):
+// workgroup k walks the (chain, sub-particle) items of chains [k Nc, (k+1) Nc), publishes the selected
+// sub-particle, its normalised log-weight omega_sel and the step weight of each of its chains to HBM, meets
+// the others at a per-sequence barrier (one agent-scope atomic counter per sequence, bounded spin), and then
+// every workgroup rebuilds the N-entry CDF and draws the ancestors of ITS OWN chains -- one barrier per step.
+// The per-item work is the arithmetic of psvo_bsim_forward (packed f32 pair loop over the LDS-staged tile).
 //
 // With omega_raw = Lambda + phi + g - q the reference's per-step weight
 //     bw_log_W = (Lambda + g)_sel - q_sel - omega_sel - log M          (PSVOwR.py:135-142)
@@ -24,6 +28,8 @@ struct WrArgs {
     float *bwX, *bwXanc, *bwW, *lseW;
     int32_t *sel_out, *anc_out;
     float *lam2_all, *om_all, *mu1_all;
+    float* omS;        // (T,B,N) workspace: omega_sel of every chain (logits of the cross-chain draw)
+    unsigned* sync;    // B barrier counters + 1 error flag (zeroed before the launch)
 };
 
 template <int DX>
@@ -31,12 +37,39 @@ struct WrSlot {
     static constexpr int kFloats = (DX <= 3) ? 4 : 8;
 };
 
-__device__ __forceinline__ void wr_lse2_merge(float& m, float& s, float m2, float s2) {
-    const float nm = fmaxf(m, m2);
-    const float a = (m == nm) ? 1.f : exp2_fast(m - nm);
-    const float b = (m2 == nm) ? 1.f : exp2_fast(m2 - nm);
-    s = s * a + s2 * b;
-    m = nm;
+// loads of data another workgroup of the cluster wrote before the barrier: agent scope (the per-XCD L2s are
+// not coherent with each other for ordinary cached loads)
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Barrier over the K workgroups of a sequence.  `target` = K * (number of barriers passed so far + 1).
+// The spin is bounded: on a timeout (or once another workgroup flagged one) the error flag is raised and every
+// later barrier falls through, so the grid always drains.
+__device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned* err, unsigned target, int K) {
+    __builtin_amdgcn_s_waitcnt(0);      // this lane's agent-scope stores have been acknowledged
+    __syncthreads();
+    if (K > 1) {
+        if (threadIdx.x == 0) {
+            // Everything the other workgroups read was written with agent-scope stores (write-through to the
+            // coherence point) and has completed (__syncthreads waits for this workgroup's stores), and it is read
+            // back with agent-scope loads: no L2 write-back / invalidate (__threadfence) is needed -- on this
+            // 8-XCD part that fence costs several microseconds per step.
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 template <int DX>
@@ -53,33 +86,35 @@ __device__ __forceinline__ void wr_read_slot(const float* p, float (&F)[DX], flo
     }
 }
 
-template <int DX, int DY, int H, int M>
-__global__ void __launch_bounds__(1024) psvowr_fwd_kernel(const WrArgs a) {
+template <int DX, int DY, int H, int M, int MAXT>
+__global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
     constexpr int PS = WrSlot<DX>::kFloats;
     constexpr bool kRolled = true;
+    constexpr int JB = (MAXT > 256) ? 4 : 16;      // pair-loop block (entries held in registers; 128 VGPRs at 1024 lanes)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NTB = blockDim.x, nw = NTB >> 6;
     const int B = a.B, T = a.T, N = a.N;
-    const int NP = (N + 3) & ~3;
-    const int b = blockIdx.x;
+    const int NP = ((N + 4 * JB - 1) / (4 * JB)) * (4 * JB);   // tile padded to whole blocks of JB entries
+    const int b = blockIdx.y, kb = blockIdx.x, K = gridDim.x;
+    const int Nc = (N + K - 1) / K;                // chains per workgroup
+    const int c0 = kb * Nc, c1 = min(N, c0 + Nc);  // this workgroup's chains
     const int cpr = NTB / M;                       // chains per round
-    const int rounds = (N + cpr - 1) / cpr;
+    const int rounds = (Nc + cpr - 1) / cpr;
     const int cl = tid / M, m = tid % M, q = m & 3;
     const int gbase = lane - m;
+    unsigned* const bar = a.sync + b;
+    unsigned* const err = a.sync + B;
 
     float* wf = smem;
     float* wg = wf + MQ::kSize;
     float* wqi = wg + MG::kSize;
     float* tile = wqi + MQ::kSize;                 // [2][NP][PS]
-    float* xanc = tile + 2 * NP * PS;              // [DX][N]  resampled chain states (x_{t+1} of every chain)
-    float* xsel = xanc + DX * N;                   // [DX][N]  selected sub-particle of every chain
-    float* omsel = xsel + DX * N;                  // [N]      its normalised log-weight (logits of the cross-chain draw)
-    float* wsel = omsel + N;                       // [N]      per-step weight bw_log_W
-    float* cdf = wsel + N;                         // [N]
+    float* xanc = tile + 2 * NP * PS;              // [DX][Nc] resampled states (x_{t+1}) of this workgroup's chains
+    float* cdf = xanc + DX * Nc;                   // [N]      CDF of the cross-chain draw
     float* red = cdf + N;                          // 64 floats scratch
 
     MQ::load(wf, a.f, tid, NTB);
@@ -125,7 +160,6 @@ __global__ void __launch_bounds__(1024) psvowr_fwd_kernel(const WrArgs a) {
         mi[d] = a.minit[b * DX + d];
     }
     const float logM = logf((float)M);
-    const float logN = logf((float)N);
     const float ninf = -__builtin_huge_valf();
 
     auto stage = [&](int tt, float* buf) {  // forward tile of step tt: (F', W') slots
@@ -153,6 +187,7 @@ __global__ void __launch_bounds__(1024) psvowr_fwd_kernel(const WrArgs a) {
     if (T >= 2) stage(T - 2, tile);
     __syncthreads();
 
+    unsigned nbar = 0;
     for (int t = T - 1; t >= 0; --t) {
         const size_t tb = (size_t)t * B + b;
         const float* cur = tile + ((T - 1 - t) & 1) * NP * PS;
@@ -167,13 +202,14 @@ __global__ void __launch_bounds__(1024) psvowr_fwd_kernel(const WrArgs a) {
         for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
 
         for (int r = 0; r < rounds; ++r) {
-            const int n_raw = r * cpr + cl;
-            const bool valid = n_raw < N;
-            const int n = valid ? n_raw : N - 1;
+            const int n_raw = c0 + r * cpr + cl;
+            const bool valid = n_raw < c1 && (r * cpr + cl) < Nc;
+            const int n = valid ? n_raw : max(c1 - 1, 0);
+            const int nl = n - c0;                 // index inside this workgroup's chains
             float xp[DX], eps[DX];
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
-                xp[d] = last ? 0.f : xanc[d * N + n];
+                xp[d] = last ? 0.f : xanc[d * Nc + nl];
                 eps[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
             }
             // ---- proposal ------------------------------------------------------------------------
@@ -214,51 +250,68 @@ __global__ void __launch_bounds__(1024) psvowr_fwd_kernel(const WrArgs a) {
             MG::template eval<kRolled>(wg, x, gm);
             const float g_lp = diag_lp<DY>(y, gm, isg, kg);
 
-            // ---- filter term over the LDS tile (quad register blocking, online lse in log2) ----------------
+            // ---- filter term over the LDS tile: quad register blocking, packed f32, block-wise log-sum-exp --------
             float lam;
             if (t >= 1) {
-                float xq[4][DX];
+                f2 xa[DX], xb[DX];
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
                     float t4[4];
                     quad_bcast4(x[d] * rp[d], t4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xq[i][d] = t4[i];
+                    xa[d] = f2{t4[0], t4[1]};
+                    xb[d] = f2{t4[2], t4[3]};
                 }
-                float mx[4], sm[4];
+                f2 mxa = f2{ninf, ninf}, mxb = mxa, sma = f2{0.f, 0.f}, smb = sma;
+                const int nq = NP >> 2;            // a multiple of JB
+                for (int k0 = 0; k0 < nq; k0 += JB) {
+                    f2 va[JB], vb[JB];
+                    f2 bma = f2{ninf, ninf}, bmb = bma;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    mx[i] = ninf;
-                    sm[i] = 0.f;
-                }
-                const int nq = NP >> 2;
-                for (int jj = 0; jj < nq; ++jj) {
-                    float F[DX], W;
-                    wr_read_slot<DX>(cur + (jj * 4 + q) * PS, F, W);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float acc = W;
+                    for (int c = 0; c < JB; ++c) {
+                        float F[DX], W;
+                        wr_read_slot<DX>(cur + ((k0 + c) * 4 + q) * PS, F, W);
+                        f2 la = f2{W, W}, lb = la;
 #pragma unroll
                         for (int d = 0; d < DX; ++d) {
-                            const float df = xq[i][d] - F[d];
-                            acc = fmaf(-df, df, acc);
+                            const f2 Fd = f2{F[d], F[d]};
+                            const f2 ua = xa[d] - Fd, ub = xb[d] - Fd;
+                            la = pk_fma(-ua, ua, la);
+                            lb = pk_fma(-ub, ub, lb);
                         }
-                        const float nm = fmaxf(mx[i], acc);
-                        const float base = (nm == ninf) ? 0.f : nm;
-                        sm[i] = sm[i] * exp2_fast(mx[i] - base) + exp2_fast(acc - base);
-                        mx[i] = nm;
+                        va[c] = la;
+                        vb[c] = lb;
+                        bma = pk_max(bma, la);
+                        bmb = pk_max(bmb, lb);
                     }
+                    const f2 nma = pk_max(mxa, bma), nmb = pk_max(mxb, bmb);
+                    const f2 ba = f2{nma.x == ninf ? 0.f : nma.x, nma.y == ninf ? 0.f : nma.y};
+                    const f2 bb = f2{nmb.x == ninf ? 0.f : nmb.x, nmb.y == ninf ? 0.f : nmb.y};
+                    const f2 ra = mxa - ba, rb = mxb - bb;
+                    sma = sma * f2{exp2_fast(ra.x), exp2_fast(ra.y)};
+                    smb = smb * f2{exp2_fast(rb.x), exp2_fast(rb.y)};
+#pragma unroll
+                    for (int c = 0; c < JB; ++c) {
+                        const f2 da = va[c] - ba, db = vb[c] - bb;
+                        sma += f2{exp2_fast(da.x), exp2_fast(da.y)};
+                        smb += f2{exp2_fast(db.x), exp2_fast(db.y)};
+                    }
+                    mxa = nma;
+                    mxb = nmb;
                 }
+                const float mx[4] = {mxa.x, mxa.y, mxb.x, mxb.y};
+                const float sm[4] = {sma.x, sma.y, smb.x, smb.y};
                 float lm = ninf, ls = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float mm = mx[i], ss = sm[i];
-                    wr_lse2_merge(mm, ss, xor_lane<1>(mx[i]), xor_lane<1>(sm[i]));
-                    const float m2 = xor_lane<2>(mm), s2 = xor_lane<2>(ss);
-                    wr_lse2_merge(mm, ss, m2, s2);
+                for (int i = 0; i < 4; ++i) {   // merge the quad's four j-slices; lane q keeps sub-particle i == q
+                    float gmx = fmaxf(mx[i], xor_lane<1>(mx[i]));
+                    gmx = fmaxf(gmx, xor_lane<2>(gmx));
+                    const float base = (gmx == ninf) ? 0.f : gmx;
+                    float sc = sm[i] * exp2_fast(mx[i] - base);
+                    sc += xor_lane<1>(sc);
+                    sc += xor_lane<2>(sc);
                     if (i == q) {
-                        lm = mm;
-                        ls = ss;
+                        lm = gmx;
+                        ls = sc;
                     }
                 }
                 const float lam2 = lm + log2_fast(ls);
@@ -293,26 +346,22 @@ __global__ void __launch_bounds__(1024) psvowr_fwd_kernel(const WrArgs a) {
             const float om_s = __shfl(omega, src);
             const float phi_s = __shfl(phi, src);
             const float bw = lse_m - phi_s - logM;   // == (Lambda + g)_sel - q_sel - omega_sel - log M
-            if (valid && m == 0) {
+            if (valid && m == 0) {                   // published to the cluster through HBM
 #pragma unroll
-                for (int d = 0; d < DX; ++d) {
-                    xsel[d * N + n] = xs[d];
-                    a.bwX[(tb * DX + d) * N + n] = xs[d];
-                }
-                omsel[n] = om_s;
-                wsel[n] = bw;
-                a.bwW[tb * N + n] = bw;
+                for (int d = 0; d < DX; ++d) st_agent(a.bwX + (tb * DX + d) * N + n, xs[d]);
+                st_agent(a.omS + tb * N + n, om_s);
+                st_agent(a.bwW + tb * N + n, bw);
                 a.sel_out[tb * N + n] = sel;
             }
         }
-        __syncthreads();
+        cluster_barrier(bar, err, (unsigned)K * (++nbar), K);
 
-        // ---- resample the chains: a[k] ~ Categorical(softmax_n omega_sel[n]), k = 0..N-1 (PSVOwR.py:103,145,185) ----
+        // ---- resample the chains: a[k] ~ Categorical(softmax_n omega_sel[n]) (PSVOwR.py:103,145,185); every workgroup
+        //      rebuilds the CDF over all N chains and draws the ancestors of its own ----------------------------------
         {
             const bool act = tid < N;
-            const float lo = act ? omsel[tid] : ninf;
-            const float lw = act ? wsel[tid] : ninf;
-            // block max of both vectors
+            const float lo = act ? ld_agent(a.omS + tb * N + tid) : ninf;
+            const float lw = (act && kb == 0) ? ld_agent(a.bwW + tb * N + tid) : ninf;
             float m1 = wave_max(lo), m2 = wave_max(lw);
             if (lane == 0) {
                 red[wave] = m1;
@@ -326,7 +375,7 @@ __global__ void __launch_bounds__(1024) psvowr_fwd_kernel(const WrArgs a) {
             }
             __syncthreads();
             const float w = act ? expf(lo - mo) : 0.f;
-            const float ew = act ? expf(lw - mw) : 0.f;
+            const float ew = (act && kb == 0) ? expf(lw - mw) : 0.f;
             float sc = wave_incl_scan(w, lane);
             const float sw = wave_sum(ew);
             if (lane == 63) red[wave] = sc;
@@ -341,14 +390,15 @@ __global__ void __launch_bounds__(1024) psvowr_fwd_kernel(const WrArgs a) {
             }
             sc += off;
             if (act) cdf[tid] = sc;
-            if (tid == 0) a.lseW[tb] = mw + logf(totw);   // logsumexp_n bw_log_W[t, :, b]
+            if (tid == 0 && kb == 0) a.lseW[tb] = mw + logf(totw);   // logsumexp_n bw_log_W[t, :, b]
             __syncthreads();
-            if (act) {
+            const int k = c0 + tid;                 // own chain whose ancestor this lane draws
+            if (tid < Nc && k < c1) {
                 int anc;
                 if (a.anc_in) {
-                    anc = a.anc_in[tb * N + tid];
+                    anc = a.anc_in[tb * N + k];
                 } else {
-                    const float target = a.u_r[tb * N + tid] * tot;
+                    const float target = a.u_r[tb * N + k] * tot;
                     int pos = 0;
                     for (int s = 1 << (31 - __clz(N)); s > 0; s >>= 1) {
                         const int p = pos + s;
@@ -356,15 +406,14 @@ __global__ void __launch_bounds__(1024) psvowr_fwd_kernel(const WrArgs a) {
                     }
                     anc = min(pos, N - 1);
                 }
-                a.anc_out[tb * N + tid] = anc;
+                a.anc_out[tb * N + k] = anc;
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
-                    const float v = xsel[d * N + anc];
-                    xanc[d * N + tid] = v;          // (xanc is only read in the item rounds, after the barrier)
-                    a.bwXanc[(tb * DX + d) * N + tid] = v;
+                    const float v = ld_agent(a.bwX + (tb * DX + d) * N + anc);
+                    xanc[d * Nc + tid] = v;         // (xanc is only read in the item rounds, after the barrier)
+                    a.bwXanc[(tb * DX + d) * N + k] = v;
                 }
             }
-            (void)logN;
         }
         __syncthreads();
     }
@@ -375,15 +424,33 @@ static int launch_wr_fwd(const WrArgs& a, hipStream_t stream) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
     constexpr int PS = WrSlot<DX>::kFloats;
-    const int NP = (a.N + 3) & ~3;
-    long long items = (long long)a.N * M;
+    const int K = wr_cluster(a.B, a.N, M);
+    const int Nc = (a.N + K - 1) / K;
+    long long items = (long long)Nc * M;
     int NTB = (int)(((items + 63) / 64) * 64);
+    const int NN = (a.N + 63) & ~63;               // the cross-chain draw uses one lane per chain
+    if (NTB < NN) NTB = NN;
     if (NTB > 1024) NTB = 1024;
-    if (a.N > NTB) return PSVO_ERR_UNSUPPORTED;   // the cross-chain draw uses one lane per chain
-    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (2 * DX + 3) * (size_t)a.N + 64);
+    if (a.N > NTB) return PSVO_ERR_UNSUPPORTED;
+    const int JB = NTB > 256 ? 4 : 16;
+    const int NP = ((a.N + 4 * JB - 1) / (4 * JB)) * (4 * JB);
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)DX * Nc + a.N + 64);
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
-    hipLaunchKernelGGL((psvowr_fwd_kernel<DX, DY, H, M>), dim3(a.B), dim3(NTB), lds, stream, a);
+    if (hipMemsetAsync(a.sync, 0, sizeof(unsigned) * (a.B + 1), stream) != hipSuccess) return launch_status();
+    WrArgs args = a;
+    void* kargs[] = {(void*)&args};
+    const dim3 grid(K, a.B), block(NTB);
+    hipError_t e;
+    if (NTB > 256)
+        e = hipLaunchCooperativeKernel((const void*)psvowr_fwd_kernel<DX, DY, H, M, 1024>, grid, block, kargs, lds, stream);
+    else
+        e = hipLaunchCooperativeKernel((const void*)psvowr_fwd_kernel<DX, DY, H, M, 256>, grid, block, kargs, lds, stream);
+    if (e != hipSuccess) {
+        g_last_hip_error = e;
+        (void)hipGetLastError();
+        return PSVO_ERR_HIP;
+    }
     return launch_status();
 }
 
@@ -419,6 +486,10 @@ static int wr_dispatch_dy(const WrArgs& a, int Dy, int H, int M, hipStream_t s) 
 
 }  // namespace psvo
 
+extern "C" int psvo_bsimwr_blocks(int B, int N, int M) { return psvo::wr_cluster(B, N, M); }
+
+extern "C" long long psvo_bsimwr_ws_floats(int B, int T, int N) { return (long long)T * B * N + B + 1; }
+
 extern "C" int psvo_bsimwr_forward(const psvo_desc* desc, const float* Fm, const float* logW, const float* lse,
                                    const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv, const float* sig_f,
                                    const float* sig_g, const float* sig_q1inv, const float* sig_bq2, const float* bmu2,
@@ -426,11 +497,11 @@ extern "C" int psvo_bsimwr_forward(const psvo_desc* desc, const float* Fm, const
                                    const float* obs, const float* eps_b, const float* u_b, const float* u_r,
                                    const int32_t* sel_in, const int32_t* anc_in, float* bwX, float* bwXanc, float* bwW,
                                    float* lseW, int32_t* sel_out, int32_t* anc_out, float* lam2_all, float* om_all,
-                                   float* mu1_all, void* stream) {
+                                   float* mu1_all, float* ws, void* stream) {
     using namespace psvo;
     if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 || !bmu2 ||
         !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwX || !bwXanc || !bwW || !lseW || !sel_out ||
-        !anc_out)
+        !anc_out || !ws)
         return PSVO_ERR_INVALID;
     if ((!u_b && !sel_in) || (!u_r && !anc_in)) return PSVO_ERR_INVALID;
     if (desc->B <= 0 || desc->T < 2 || desc->N <= 0 || desc->M <= 0) return PSVO_ERR_INVALID;
@@ -444,6 +515,8 @@ extern "C" int psvo_bsimwr_forward(const psvo_desc* desc, const float* Fm, const
     a.obs = obs; a.eps_b = eps_b; a.u_b = u_b; a.u_r = u_r; a.sel_in = sel_in; a.anc_in = anc_in;
     a.bwX = bwX; a.bwXanc = bwXanc; a.bwW = bwW; a.lseW = lseW; a.sel_out = sel_out; a.anc_out = anc_out;
     a.lam2_all = lam2_all; a.om_all = om_all; a.mu1_all = mu1_all;
+    a.omS = ws;
+    a.sync = reinterpret_cast<unsigned*>(ws + (size_t)desc->T * desc->B * desc->N);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {
         case 2: return wr_dispatch_dy<2>(a, desc->Dy, desc->H, desc->M, s);

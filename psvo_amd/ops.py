@@ -377,7 +377,9 @@ def bsimwr_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, b
     out = {"bwX": z(T, B, Dx, N), "bwXanc": z(T, B, Dx, N), "bwW": z(T, B, N), "lseW": z(T, B),
            "sel": zi(T, B, N), "anc": zi(T, B, N),
            "lam2": z(T, B, N, M) if save else None, "om": z(T, B, N, M) if save else None,
-           "mu1": z(T, B, Dx, N) if save else None}
+           "mu1": z(T, B, Dx, N) if save else None,
+           # workspace; its last word (viewed as int32) is nonzero iff a cluster barrier timed out
+           "ws": z(lib.psvo_bsimwr_ws_floats(B, T, N))}
     _mark("psvo_bsimwr_forward", 0)
     st = lib.psvo_bsimwr_forward(
         ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
@@ -385,7 +387,7 @@ def bsimwr_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, b
         _ptr(sig_f), _ptr(sig_g), _ptr(sig_q1inv), _ptr(sig_bq2), _ptr(bmu2), _ptr(minit), _ptr(sig_init),
         _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(u_b), _ptr(u_r), _ptr(sel_in), _ptr(anc_in),
         _ptr(out["bwX"]), _ptr(out["bwXanc"]), _ptr(out["bwW"]), _ptr(out["lseW"]), _ptr(out["sel"]),
-        _ptr(out["anc"]), _ptr(out["lam2"]), _ptr(out["om"]), _ptr(out["mu1"]), _stream())
+        _ptr(out["anc"]), _ptr(out["lam2"]), _ptr(out["om"]), _ptr(out["mu1"]), _ptr(out["ws"]), _stream())
     _mark("psvo_bsimwr_forward", 1)
     _lib.check(st, "psvo_bsimwr_forward")
     return out
@@ -407,11 +409,13 @@ def bsimwr_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, 
             raise ValueError("bsimwr_backward needs bsimwr_forward(save=True) outputs (missing %s)" % k)
         _chk(bs[k], shp, k)
     z = lambda *s: _empty(*s, device=dev)
+    K = lib.psvo_bsimwr_blocks(B, N, M)
     out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
-           "dFm": z(T, B, Dx, N), "dlogW": z(T, B, N), "dlse": z(T, B), "dbmu2": z(T, B, Dx),
-           "dminit": z(B, Dx), "dimean": z(B, Dx),
-           "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx)}
-    sacc = z(B, lib.psvo_bsim_acc_size(Dx, Dy))
+           "dFm_part": z(T, B, K, Dx, N), "dlogW_part": z(T, B, K, N), "dlse_part": z(T, B, K),
+           "dbmu2_rows": z(T, B, Dx, N), "dminit_rows": z(B, Dx, N), "dimean_rows": z(B, Dx, N),
+           "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx),
+           "ws": z(lib.psvo_bsimwr_bwd_ws_floats(B, T, N, Dx))}
+    sacc = z(B, K, lib.psvo_bsim_acc_size(Dx, Dy))
     _mark("psvo_bsimwr_backward", 0)
     st = lib.psvo_bsimwr_backward(
         ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
@@ -420,11 +424,16 @@ def bsimwr_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, 
         _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(bs["bwXanc"]), _ptr(bs["bwW"]), _ptr(bs["lseW"]),
         _ptr(bs["sel"]), _ptr(bs["anc"]), _ptr(bs["lam2"]), _ptr(bs["om"]), _ptr(bs["mu1"]), _ptr(dlseW),
         _ptr(out["xt"]), _ptr(out["dFt"]), _ptr(out["dGt"]), _ptr(out["dmu1"]),
-        _ptr(out["dFm"]), _ptr(out["dlogW"]), _ptr(out["dlse"]), _ptr(out["dbmu2"]), _ptr(out["dminit"]),
-        _ptr(out["dimean"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
-        _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(sacc), _stream())
+        _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(out["dlse_part"]), _ptr(out["dbmu2_rows"]),
+        _ptr(out["dminit_rows"]), _ptr(out["dimean_rows"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]),
+        _ptr(out["dsig_q1inv"]), _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(sacc),
+        _ptr(out["ws"]), _stream())
     _mark("psvo_bsimwr_backward", 1)
     _lib.check(st, "psvo_bsimwr_backward")
+    # fold the per-workgroup partials that feed the filter's reverse pass, then let the caller publish them
+    out["dFm"] = out["dFm_part"].sum(2)
+    out["dlogW"] = out["dlogW_part"].sum(2)
+    out["dlse"] = out["dlse_part"].sum(2)
     if after_kernel is not None:
         after_kernel()
     gb = gbufs or (None, None, None)

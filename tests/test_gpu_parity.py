@@ -110,6 +110,7 @@ def test_teacher_forced_parity(built_lib, case):
         assert torch.allclose(Hh.part_to_ref(bs["bwXanc"]), ref["bw_X_ancestors"], atol=2e-4, rtol=1e-5)
         assert torch.allclose(Hh.w_to_ref(bs["bwW"]), ref["bw_log_W"], atol=5e-4, rtol=1e-5)
         assert torch.allclose(bs["lseW"].double().cpu(), torch.logsumexp(ref["bw_log_W"], 1), atol=5e-4, rtol=1e-5)
+        assert int(bs["ws"][-1:].view(torch.int32)) == 0, "a cluster barrier of psvo_bsimwr_forward timed out"
     assert torch.allclose(log["Xs"].double().cpu(), ref["Xs"], atol=2e-4, rtol=1e-5)
     assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
 
@@ -133,6 +134,7 @@ def test_free_running_indices(built_lib, case):
     if obj == "PSVOwR":
         anc = log["bsim"]["anc"].permute(0, 2, 1).cpu().long()
         assert (anc != ref["idx_r"]).float().mean() == 0.0
+        assert int(log["bsim"]["ws"][-1:].view(torch.int32)) == 0, "a cluster barrier timed out"
     assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
     assert torch.allclose(log["Xs"].double().cpu(), ref["Xs"], atol=2e-4, rtol=1e-5)
 
