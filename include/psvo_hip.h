@@ -283,6 +283,22 @@ int psvo_filter_backward(const psvo_desc* desc,
                          float* sacc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * One-hidden-layer MLP over plain rows (the hoisted per-(sequence, step) networks q0, q2, BSim_q2,
+ * BSim_q_init): tf_mvn.mean of MLP_transformation, reference src/transformation/MLP.py:48-68 as called
+ * from src/SMC/SVO.py:80-84,134-138 and src/SMC/PSVO.py:86-87,120-122.
+ *   X (R,Din) row-major, out / dOut (R,Dout); Din <= 128, H in {16,32,64}, Dout <= 4.
+ *   forward : out = relu(X W1 + b1) W2 + b2.
+ *   backward: dX (R,Din) (NULL = not needed) and grad = [dW1 | db1 | dW2 | db2] (keras layout, flat;
+ *             accumulate != 0 adds into it); partial: workspace, psvo_rows_mlp_blocks(R) * len(grad) floats.
+ * ------------------------------------------------------------------------------------------- */
+int psvo_rows_mlp_blocks(long long R);
+int psvo_rows_mlp_forward(long long R, int Din, int H, int Dout, const float* X, const psvo_mlp* w,
+                          float* out, void* stream);
+int psvo_rows_mlp_backward(long long R, int Din, int H, int Dout, const float* X, const float* dOut,
+                           const psvo_mlp* w, float* dX, float* partial, float* grad, int accumulate,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Parameter gradients of a one-hidden-layer MLP from per-row output gradients:
  *   grad = [dW1 (Din,H) | db1 (H) | dW2 (H,Dout) | db2 (Dout)]  (keras layout, flat)
  *   X [S][Din][L], dOut [S][Dout][L]: S segments of L rows ((T,B,D,N) tensors: S = T*B, L = N).

@@ -53,6 +53,10 @@ SIGNATURES = {
     "psvo_bsimwr_forward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 25 + [_P]),
     "psvo_bsimwr_bwd_ws_floats": (ctypes.c_longlong, [ctypes.c_int] * 4),
     "psvo_bsimwr_backward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 39),
+    "psvo_rows_mlp_blocks": (ctypes.c_int, [ctypes.c_longlong]),
+    "psvo_rows_mlp_forward": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _MLP, _P, _P]),
+    "psvo_rows_mlp_backward": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _MLP,
+                                              _P, _P, _P, ctypes.c_int, _P]),
     "psvo_bilstm_forward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 8 + [_P]),
     "psvo_bilstm_backward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 10 + [_P]),
     "psvo_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,

@@ -107,9 +107,13 @@ class FilterFunction(torch.autograd.Function):
             main = torch.cuda.current_stream()
             side.wait_event(ready)
 
-            def before_wgrad():   # the bsim weight gradients accumulate into the same q1 / g slices on the main stream
-                if ov.bsim_wgrad_done is not None:
-                    side.wait_event(ov.bsim_wgrad_done)
+            entered = torch.cuda.Event()
+            entered.record(main)
+
+            def before_wgrad():
+                # everything the main stream issued before this node accumulates into the same flat-gradient slices
+                # (bsim weight gradients: f, g; a hoisted f.mean(mu_0)): the filter's weight gradients go after it
+                side.wait_event(entered)
             with ops.launch_on(side):
                 r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
                                         obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
@@ -239,6 +243,31 @@ class BsimWRFunction(torch.autograd.Function):
         return (None,) * 7 + (r["dFm"], r["dlogW"], r["dlse"]) + tuple(gf) + tuple(gg) + tuple(gq) + (
             r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_rows"].sum(-1),
             r["dminit_rows"].sum(-1), r["dsig_init"], r["dimean_rows"].sum(-1), r["disig"])
+
+
+class RowsMLPFunction(torch.autograd.Function):
+    """psvo_rows_mlp_forward / psvo_rows_mlp_backward: a hoisted one-hidden-layer MLP over (R, Din) rows.
+    apply(gbuf, X, W1, b1, W2, b2) -> (R, Dout); gbuf = slice of the flat gradient buffer to accumulate
+    [dW1|db1|dW2|db2] into directly, or None."""
+
+    @staticmethod
+    def forward(ctx, gbuf, X, W1, b1, W2, b2):
+        ctx.gbuf = gbuf
+        X = _cf(X)
+        w = tuple(_cf(v) for v in (W1, b1, W2, b2))
+        ctx.saved = (X, w)
+        ctx.need_dX = ctx.needs_input_grad[1]
+        return ops.rows_mlp_forward(X, w)
+
+    @staticmethod
+    def backward(ctx, dOut):
+        X, w = ctx.saved
+        Din, H = w[0].shape
+        Dout = w[2].shape[1]
+        dX, g = ops.rows_mlp_backward(X, _cg(dOut).float(), w, need_dX=ctx.need_dX, grad=ctx.gbuf)
+        if ctx.gbuf is not None:
+            return None, dX, None, None, None, None
+        return (None, dX) + tuple(ops.split_mlp_grad(g, Din, H, Dout))
 
 
 class BiLSTMFunction(torch.autograd.Function):

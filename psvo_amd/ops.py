@@ -259,6 +259,42 @@ def mlp_wgrad(X, dOut, w, Din, H, Dout, grad=None, axis=2):
     return grad
 
 
+def rows_mlp_forward(X, w):
+    """psvo_rows_mlp_forward: X (R, Din) -> (R, Dout); w = (W1 (Din,H), b1, W2 (H,Dout), b2)."""
+    lib = _lib.load()
+    R, Din = X.shape
+    H, Dout = w[2].shape
+    _chk(X, (R, Din), "X")
+    ws = _mlp_struct(w, Din, H, Dout, "w")
+    out = _empty(R, Dout, device=X.device)
+    _mark("psvo_rows_mlp_forward", 0)
+    st = lib.psvo_rows_mlp_forward(R, Din, H, Dout, _ptr(X), ctypes.byref(ws), _ptr(out), _stream())
+    _mark("psvo_rows_mlp_forward", 1)
+    _lib.check(st, "psvo_rows_mlp_forward")
+    return out
+
+
+def rows_mlp_backward(X, dOut, w, need_dX=True, grad=None):
+    """psvo_rows_mlp_backward -> (dX (R,Din) or None, flat grad [dW1|db1|dW2|db2]); `grad` given: accumulate."""
+    lib = _lib.load()
+    R, Din = X.shape
+    H, Dout = w[2].shape
+    _chk(X, (R, Din), "X"); _chk(dOut, (R, Dout), "dOut")
+    ws = _mlp_struct(w, Din, H, Dout, "w")
+    NP = Din * H + H + H * Dout + Dout
+    dX = _empty(R, Din, device=X.device) if need_dX else None
+    partial = _empty(lib.psvo_rows_mlp_blocks(R), NP, device=X.device)
+    acc = grad is not None
+    if grad is None:
+        grad = _empty(NP, device=X.device)
+    _mark("psvo_rows_mlp_backward", 0)
+    st = lib.psvo_rows_mlp_backward(R, Din, H, Dout, _ptr(X), _ptr(dOut), ctypes.byref(ws), _ptr(dX), _ptr(partial),
+                                    _ptr(grad), int(acc), _stream())
+    _mark("psvo_rows_mlp_backward", 1)
+    _lib.check(st, "psvo_rows_mlp_backward")
+    return dX, grad
+
+
 def split_mlp_grad(g, Din, H, Dout):
     """flat [dW1|db1|dW2|db2] -> (dW1 (Din,H), db1 (H), dW2 (H,Dout), db2 (Dout)) views."""
     a = Din * H

@@ -41,6 +41,14 @@ class MLP_transformation(nn.Module):
 
     def transform(self, Input):
         """reference MLP.py:48-68; returns (mu, None)."""
+        if (Input.is_cuda and len(self.Dhs) == 1 and not self.use_residual and self.Dhs[0] in (16, 32, 64)
+                and Input.shape[-1] <= 128 and self.mu_kernel.shape[1] <= 4 and Input.dtype == torch.float32):
+            # one native launch forward, one backward (psvo_rows_mlp_*) instead of ~5 + ~15 torch kernels
+            from ..autograd import RowsMLPFunction
+            X = Input.reshape(-1, Input.shape[-1])
+            mu = RowsMLPFunction.apply(self.__dict__.get("_flat_grad"), X, self.kernels[0], self.biases[0],
+                                       self.mu_kernel, self.mu_bias)
+            return mu.reshape(Input.shape[:-1] + (mu.shape[-1],)), None
         hidden = Input
         for W, b in zip(self.kernels, self.biases):
             hidden = torch.relu(hidden @ W + b)

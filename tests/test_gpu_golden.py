@@ -176,3 +176,31 @@ def test_flat_buffer_gradients_match_autograd_path(built_lib, obj):
     for n, g in outs[0][1].items():
         g2 = outs[1][1][n]
         assert torch.allclose(g, g2, atol=2e-5 + 1e-4 * float(g.abs().max()), rtol=1e-3), n
+
+
+@pytest.mark.parametrize("R,Din,H,Dout", [(6400, 64, 32, 2), (32, 1, 32, 2), (77, 128, 64, 4), (1000, 3, 16, 1)])
+def test_rows_mlp_matches_torch(built_lib, R, Din, H, Dout):
+    """psvo_rows_mlp_forward / _backward (the hoisted q0 / q2 / BSim_q2 / BSim_q_init means) against the same MLP
+    in plain PyTorch fp32: values atol 1e-5 (relative to the output scale), all gradients rel 1e-4."""
+    from psvo_amd.autograd import RowsMLPFunction
+    g = torch.Generator().manual_seed(R + Din)
+    X = torch.randn(R, Din, generator=g).cuda().requires_grad_(True)
+    W1 = (torch.randn(Din, H, generator=g) / Din ** 0.5).cuda().requires_grad_(True)
+    b1 = (0.3 * torch.randn(H, generator=g)).cuda().requires_grad_(True)
+    W2 = (torch.randn(H, Dout, generator=g) / H ** 0.5).cuda().requires_grad_(True)
+    b2 = (0.3 * torch.randn(Dout, generator=g)).cuda().requires_grad_(True)
+    dOut = torch.randn(R, Dout, generator=g).cuda()
+    out = RowsMLPFunction.apply(None, X, W1, b1, W2, b2)
+    ref = torch.relu(X @ W1 + b1) @ W2 + b2
+    assert torch.allclose(out, ref, atol=1e-5 * max(1.0, float(ref.abs().max())), rtol=1e-5)
+    grads = torch.autograd.grad(out, [X, W1, b1, W2, b2], dOut)
+    grads_ref = torch.autograd.grad(ref, [X, W1, b1, W2, b2], dOut)
+    for a_, b_ in zip(grads, grads_ref):
+        assert (a_ - b_).abs().max() <= 1e-4 * max(1.0, float(b_.abs().max()))
+    # accumulation into a given flat gradient slice, no dX requested
+    NP = Din * H + H + H * Dout + Dout
+    flat = torch.ones(NP, device="cuda")
+    out2 = RowsMLPFunction.apply(flat, X.detach(), W1, b1, W2, b2)
+    out2.backward(dOut)
+    want = torch.cat([t.reshape(-1) for t in grads_ref[1:]]) + 1.0
+    assert (flat - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max()))
