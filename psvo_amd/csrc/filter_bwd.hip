@@ -382,6 +382,300 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Four lanes per particle (N <= 128), mirror of filter_fwd_lpp_kernel: lane p of the quad owns hidden units
+// [p H/4, (p+1) H/4) of every MLP (forward recompute and input gradient), the partial input gradients are summed
+// over the quad with two DPP adds; everything that is not an MLP is computed redundantly in the four lanes and
+// counted once (lane p == 0) in the sums.  The reverse filter is on the critical path of a training step and its
+// step is a dependent chain, so shortening the two MLP input-gradient chains is what matters.
+// ---------------------------------------------------------------------------------------------
+template <int DX, int DY, int H>
+__global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs a) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    using AC = FAcc<DX, DY>;
+    constexpr int P = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = blockDim.x, nw = NT >> 6;
+    const int NPT = NT / P;
+    const int b = blockIdx.x, B = a.B, T = a.T, N = a.N;
+    const int pn = tid >> 2, p = tid & 3;
+    const bool valid = pn < N;
+    const bool one = valid && p == 0;          // the lane of the quad that counts in sums over particles
+    const int n = valid ? pn : N - 1;
+
+    float* wq1 = smem;
+    float* wf = wq1 + MQ::kSize;
+    float* wg = wf + MQ::kSize;
+    float* accP = wg + MG::kSize;        // [2][DX][NPT] scatter targets d P1 (+ d Fm when bootstrap)
+    float* accF = accP + 2 * DX * NPT;   // [2][DX][NPT] d Fm (only when !bootstrap)
+    float* red = accF + 2 * DX * NPT;    // 16 floats
+
+    MQ::load(wq1, a.q1, tid, NT);
+    if (!a.bootstrap) MQ::load(wf, a.f, tid, NT);
+    MG::load(wg, a.g, tid, NT);
+    const float* wfm = a.bootstrap ? wq1 : wf;
+    for (int i = tid; i < 4 * DX * NPT; i += NT) accP[i] = 0.f;
+
+    float sq1[DX], sq2[DX], sfv[DX], s0[DX], fs0[DX], isg[DY];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        sq1[d] = a.sig_q1[d];
+        sq2[d] = a.two_q ? a.sig_q2[d] : 1.f;
+        sfv[d] = a.bootstrap ? a.sig_q1[d] : a.sig_f[d];
+        s0[d] = a.sig0[d];
+        fs0[d] = a.fsig0[d];
+    }
+#pragma unroll
+    for (int e = 0; e < DY; ++e) isg[e] = 1.f / a.sig_g[e];
+    const BStepK<DX> K0 = make_bstepk<DX>(s0, sq2, fs0, a.two_q != 0);
+    const BStepK<DX> K1 = make_bstepk<DX>(sq1, sq2, sfv, a.two_q != 0);
+
+    float acc[AC::kN];
+#pragma unroll
+    for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
+    float dlnw = 0.f;
+
+    float m0r[DX], fm0r[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        m0r[d] = a.m0[b * DX + d];
+        fm0r[d] = a.fm0[b * DX + d];
+    }
+    auto load_anc = [&](int t) -> int {
+        return (t >= 1 && a.resample) ? a.idx[((size_t)(t - 1) * B + b) * N + n] : n;
+    };
+    const bool one_part = (a.nparts == 1);
+    // issue-only prefetch (see filter_bwd_kernel)
+    auto load_step = [&](int t, int anc, float (&sx)[DX], float (&se)[DX], float (&sm2)[DX], float (&sy)[DY],
+                         float (&smean1)[DX], float (&sfmean)[DX], float (&sdfm)[DX], float (&ssc)[4]) {
+        const size_t tb = (size_t)t * B + b;
+        const size_t tp = (t == 0) ? tb : tb - B;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            sx[d] = a.X[(tb * DX + d) * N + n];
+            se[d] = a.eps[(tb * DX + d) * N + n];
+            sm2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
+            sfmean[d] = a.Fm[(tp * DX + d) * N + anc];
+            smean1[d] = a.bootstrap ? 0.f : a.P1[(tp * DX + d) * N + anc];
+            if (a.dFm_ext) {
+                if (one_part) {
+                    sdfm[d] = a.dFm_ext[(tb * DX + d) * N + n];
+                } else {
+                    float ext = 0.f;
+                    for (int q = 0; q < a.nparts; ++q) ext += a.dFm_ext[((tb * a.nparts + q) * DX + d) * N + n];
+                    sdfm[d] = ext;
+                }
+            } else {
+                sdfm[d] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) sy[k] = a.obs[tb * DY + k];
+        ssc[0] = a.logW[tb * N + n];
+        ssc[1] = a.lse[tb];
+        ssc[2] = a.dlse ? a.dlse[tb] : 0.f;
+        if (a.dlogW_ext) {
+            if (one_part) {
+                ssc[3] = a.dlogW_ext[tb * N + n];
+            } else {
+                float ext = 0.f;
+                for (int q = 0; q < a.nparts; ++q) ext += a.dlogW_ext[(tb * a.nparts + q) * N + n];
+                ssc[3] = ext;
+            }
+        } else {
+            ssc[3] = 0.f;
+        }
+    };
+    float c_x[DX], c_e[DX], c_m2[DX], c_y[DY], c_mean1[DX], c_fmean[DX], c_dfm[DX], c_sc[4];
+    int c_anc = load_anc(T - 1);
+    int anc_next = load_anc(T - 2);
+    load_step(T - 1, c_anc, c_x, c_e, c_m2, c_y, c_mean1, c_fmean, c_dfm, c_sc);
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t tb = (size_t)t * B + b;
+        const bool first = (t == 0);
+        const BStepK<DX> K = first ? K0 : K1;
+        float inc[AC::kSet];
+#pragma unroll
+        for (int i = 0; i < AC::kSet; ++i) inc[i] = 0.f;
+        float* curP = accP + (t & 1) * DX * NPT;
+        float* nxtP = accP + ((t + 1) & 1) * DX * NPT;
+        float* curF = accF + (t & 1) * DX * NPT;
+        float* nxtF = accF + ((t + 1) & 1) * DX * NPT;
+
+        float n_x[DX], n_e[DX], n_m2[DX], n_y[DY], n_mean1[DX], n_fmean[DX], n_dfm[DX], n_sc[4];
+        int n_anc = n;
+        if (t >= 1) {
+            n_anc = anc_next;
+            load_step(t - 1, n_anc, n_x, n_e, n_m2, n_y, n_mean1, n_fmean, n_dfm, n_sc);
+            anc_next = load_anc(t - 2);
+        }
+        float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX];
+        const int anc = c_anc;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            x[d] = c_x[d];
+            e[d] = c_e[d];
+            m2[d] = c_m2[d];
+            fmean[d] = first ? fm0r[d] : c_fmean[d];
+            mean1[d] = first ? m0r[d] : (a.bootstrap ? c_fmean[d] : c_mean1[d]);
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) y[k] = c_y[k];
+        float mu[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d)
+            mu[d] = a.two_q ? K.c[d] * fmaf(K.i1[d], mean1[d], K.i2[d] * m2[d]) : mean1[d];
+
+        // ---- gradient w.r.t. logW_t[n] (the same in the four lanes of the particle) ---------------------------------
+        const float sm = valid ? expf(c_sc[0] - c_sc[1]) : 0.f;
+        float dlw = c_sc[2] * sm + c_sc[3];
+        if (!a.resample) {
+            const float tot = block_sum(one ? dlnw : 0.f, red, wave, lane, nw);
+            dlw += dlnw - sm * tot;
+        }
+        if (!valid) dlw = 0.f;
+        dlnw = first ? 0.f : dlw;
+        const float cnt = (p == 0) ? 1.f : 0.f;     // sums over particles take the quad's first lane
+
+        // ---- emission: hidden units of MLP_g split over the quad ----------------------------------------------------
+        float dxp[DX];                              // this lane's PARTIAL of d x (summed over the quad below)
+#pragma unroll
+        for (int d = 0; d < DX; ++d) dxp[d] = 0.f;
+        {
+            float gm[DY], dgm[DY];
+            MG::template eval_part<P>(wg, p, x, gm);
+#pragma unroll
+            for (int k = 0; k < DY; ++k) {
+                gm[k] = group_sum<P>(gm[k]);
+                const float z = (y[k] - gm[k]) * isg[k];
+                dgm[k] = dlw * z * isg[k];
+                acc[AC::kSg + k] += cnt * dlw * (z * z - 1.f) * isg[k];
+                if (valid && p == 2) a.dG[(tb * DY + k) * N + n] = dgm[k];
+            }
+            MG::template bwd_input_part<P>(wg, p, x, dgm, dxp);
+        }
+        // ---- transition and proposal densities ------------------------------------------------------------------------
+        float dfmean[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            const float z = (x[d] - fmean[d]) * K.ifs[d];
+            const float tf = dlw * z * K.ifs[d];
+            dxp[d] -= cnt * tf;
+            dfmean[d] = tf;
+            inc[AC::kSfs + d] += dlw * (z * z - 1.f) * K.ifs[d];
+            inc[AC::kSc + d] += dlw * K.ic[d];
+        }
+        // ---- MLP_q1(x_t), MLP_f(x_t): gradients scattered here by step t+1 (+ backward simulation) -----------------------
+        float dPn[DX], dFn[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            dPn[d] = curP[d * NPT + pn];
+            const float ext = c_dfm[d];
+            if (a.bootstrap) {
+                dPn[d] += ext;
+                dFn[d] = 0.f;
+            } else {
+                dFn[d] = curF[d * NPT + pn] + ext;
+            }
+            if (!valid) {
+                dPn[d] = 0.f;
+                dFn[d] = 0.f;
+            }
+        }
+        if (p == 0) {   // (only this quad reads these entries, in the wave instruction above: clear them for step t-2)
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                curP[d * NPT + pn] = 0.f;
+                if (!a.bootstrap) curF[d * NPT + pn] = 0.f;
+            }
+        }
+        if (valid) {
+            if (p == 0) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.dP[(tb * DX + d) * N + n] = dPn[d];
+            } else if (p == 1 && !a.bootstrap) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.dF[(tb * DX + d) * N + n] = dFn[d];
+            }
+        }
+        MQ::template bwd_input_part<P>(wq1, p, x, dPn, dxp);
+        if (!a.bootstrap) MQ::template bwd_input_part<P>(wfm, p, x, dFn, dxp);
+
+        // ---- x = mu + c eps, mu = c (mean1/s1 + mu2/s2) -------------------------------------------------------------------
+        float dmean1[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            const float dmu = group_sum<P>(dxp[d]);
+            inc[AC::kSc + d] += dmu * e[d];
+            if (a.two_q) {
+                dmean1[d] = dmu * K.c[d] * K.i1[d];
+                const float dm2 = dmu * K.c[d] * K.i2[d];
+                inc[AC::kSmm1 + d] += dmu * mean1[d];
+                inc[AC::kSmb + d] += dmu * m2[d];
+                inc[AC::kSmm + d] += dmu * mu[d];
+                if (valid && p == 3) a.dm2_rows[(tb * DX + d) * N + n] = dm2;
+            } else {
+                dmean1[d] = dmu;
+            }
+        }
+        // ---- gather backward: scatter-add into the parents (SVO.py:255-257), one dimension per lane of the quad --------
+        if (!first) {
+            if (valid) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    if ((d & 3) == p) {
+                        if (a.bootstrap) {
+                            atomicAdd(&nxtP[d * NPT + anc], dmean1[d] + dfmean[d]);
+                        } else {
+                            atomicAdd(&nxtP[d * NPT + anc], dmean1[d]);
+                            atomicAdd(&nxtF[d * NPT + anc], dfmean[d]);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                const float s1 = block_sum(one ? dmean1[d] : 0.f, red, wave, lane, nw);
+                const float s2 = block_sum(one ? dfmean[d] : 0.f, red, wave, lane, nw);
+                if (tid == 0) {
+                    a.dm0[b * DX + d] = s1;
+                    a.dfm0[b * DX + d] = s2;
+                }
+            }
+        }
+        if (t >= 1) {
+            c_anc = n_anc;
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                c_x[d] = n_x[d]; c_e[d] = n_e[d]; c_m2[d] = n_m2[d];
+                c_mean1[d] = n_mean1[d]; c_fmean[d] = n_fmean[d]; c_dfm[d] = n_dfm[d];
+            }
+#pragma unroll
+            for (int k = 0; k < DY; ++k) c_y[k] = n_y[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c_sc[k] = n_sc[k];
+        }
+#pragma unroll
+        for (int i = 0; i < AC::kSet; ++i) {
+            acc[i] += (first && p == 0) ? inc[i] : 0.f;
+            acc[AC::kSet + i] += (!first && p == 0) ? inc[i] : 0.f;
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < AC::kN; ++i) {
+        const float s = block_sum(valid ? acc[i] : 0.f, red, wave, lane, nw);
+        if (tid == 0) a.sacc[(size_t)b * AC::kN + i] = s;
+    }
+}
+
 // Finalize: fold the (B, NACC) sums into gradients of the scale vectors.
 //   two_q: c = 1/(1/s1 + 1/s2);  d c = Sc + Smm / c;  d(1/s1) = c*Smm1 - c^2 dc;  d(1/s2) = c*Smb - c^2 dc
 //   else : d s1 = Sc
@@ -454,7 +748,18 @@ static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipS
     const int NT = (a.N + 63) & ~63;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 4 * DX * NT + 16);
     clear_hip_error();
-    if (NT <= 256)
+    constexpr bool kLppOk = (H % 16 == 0) && (H <= 32 && DX <= 3);
+    bool lpp = false;
+    if constexpr (kLppOk) {
+        if (a.N <= 128) {   // latency-bound regime: four lanes per particle
+            const int NT4 = (4 * a.N + 63) & ~63;
+            const size_t lds4 = sizeof(float) * (2 * MQ::kSize + MG::kSize + 4 * DX * (NT4 / 4) + 16);
+            hipLaunchKernelGGL((filter_bwd_lpp_kernel<DX, DY, H>), dim3(a.B), dim3(NT4), lds4, stream, a);
+            lpp = true;
+        }
+    }
+    if (lpp) {
+    } else if (NT <= 256)
         hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, a);
     else
         hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT), lds, stream, a);
