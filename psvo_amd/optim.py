@@ -14,8 +14,22 @@ from . import _lib
 
 class FlatParams(object):
     def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        # shared parameters (f == q1 under use_bootstrap) appear once in module.parameters()
+        # Layout: the four tensors of every one-hidden-layer MLP first, as [W1 | b1 | W2 | b2] (the layout the native
+        # weight-gradient kernels write; nn.Module registration order would put mu_kernel / mu_bias first), then
+        # everything else in registration order.  Shared parameters (f == q1 under use_bootstrap) appear once.
+        from .transformation.MLP import MLP_transformation
+        self.params, seen = [], set()
+
+        def add(q):
+            if q.requires_grad and id(q) not in seen:
+                seen.add(id(q))
+                self.params.append(q)
+        for mod in module.modules():
+            if isinstance(mod, MLP_transformation) and len(mod.Dhs) == 1:
+                for q in (mod.kernels[0], mod.biases[0], mod.mu_kernel, mod.mu_bias):
+                    add(q)
+        for q in module.parameters():
+            add(q)
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.empty(n, device=dev, dtype=torch.float32)
