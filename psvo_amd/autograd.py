@@ -41,7 +41,12 @@ def side_stream(device=None):
 
 
 def _cf(t):
-    return None if t is None else t.detach().float().contiguous()
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype is not torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def _cg(t):
