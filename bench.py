@@ -142,9 +142,11 @@ def main():
     ap.add_argument("--workload", default="C*", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as one captured hipGraph instead of issuing launches eagerly (measured: "
-                         "slower here, the small kernels between the persistent ones are GPU time, not host gaps)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
+                    help="replay the step as one captured hipGraph (default): the launching Python thread needs "
+                         "~2.7 ms per C* step and more than the GPU time of the smaller workloads, and its speed "
+                         "varies with the host; eager issue is the fallback if capture fails")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="issue every launch eagerly")
     ap.add_argument("--cpu-sample-T", type=int, default=40)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
@@ -226,30 +228,37 @@ def main():
         dp.all_reduce_sum_(flat.grad)
         opt.step(lr, world_size=world)
 
-    use_graph = args.graph
+    use_graph, graph_note = args.graph, None
+    if use_graph and obj == "PSVOwR":
+        # cooperative launches (the cluster barrier needs all workgroups resident) are not captured: issue eagerly
+        use_graph, graph_note = False, "cooperative kernels are not graph-captured"
+    eager_step = train_step if args.mode == "train" else fwd_step
+    step = eager_step
     if use_graph:
-        if args.mode == "train":
-            if world == 1:
-                def whole():
-                    z = local_step()
-                    update()
-                    return z
+        try:
+            if args.mode == "train":
                 # Adam's bias-correction scalar depends on the step count: freeze it at its asymptote inside
                 # the captured launch (lr_t -> lr), which is what a long training run sees after ~5k steps
-                opt.t = 10 ** 6
-                g_step = GraphedStep(whole, generators=[smc.generator])
-                step = g_step
-            else:
-                g_local = GraphedStep(local_step, generators=[smc.generator])
+                if world == 1:
+                    def whole():
+                        z = local_step()
+                        update()
+                        return z
+                    t_saved, opt.t = opt.t, 10 ** 6
+                    step = GraphedStep(whole, generators=[smc.generator])
+                else:
+                    g_local = GraphedStep(local_step, generators=[smc.generator])
 
-                def step():
-                    z = g_local()
-                    update()
-                    return z
-        else:
-            step = GraphedStep(lambda: fwd_step().detach(), generators=[smc.generator])
-    else:
-        step = train_step if args.mode == "train" else fwd_step
+                    def step():
+                        z = g_local()
+                        update()
+                        return z
+            else:
+                step = GraphedStep(lambda: fwd_step().detach(), generators=[smc.generator])
+        except Exception as exc:     # e.g. a kernel that cannot be captured (cooperative launches): issue eagerly
+            use_graph, step = False, eager_step
+            graph_note = "graph capture failed (%s: %s)" % (type(exc).__name__, str(exc)[:120])
+            torch.cuda.synchronize()
 
     def sync():
         if dist is not None:
@@ -350,7 +359,7 @@ def main():
                                 if args.mode == "train" else "objective evaluation (ELBO + smoothed trajectories)"),
                        "global_batch": B * world, "parallelism": "dp%d (batch of sequences sharded)" % world,
                        "elbo": elbo, "forward_only_particle_steps_per_s": other,
-                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "launch": "hipGraph replay" if use_graph else ("eager" + ("; " + graph_note if graph_note else "")),
                        "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())},
                        "native_timeline_ms": timeline},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
