@@ -287,7 +287,8 @@ def main():
     elapsed, z = timed(step, args.steps, False)
     elbo = float(z.detach())
     eager = train_step if args.mode == "train" else fwd_step
-    eager()
+    for _ in range(3):      # (after graph replay the eager path first has to populate its own allocator pool)
+        eager()
     ev_steps = max(3, min(args.steps, 10))
     ops.set_timing_hook(hook)
     timed(eager, ev_steps, True)
@@ -305,7 +306,9 @@ def main():
         kms = {}
         for name, evs in events.items():
             d = [evs[i].elapsed_time(evs[i + 1]) for i in range(0, len(evs) - 1, 2)]
-            kms[name] = (sum(d) / ev_steps, len(d) / ev_steps)       # ms per step (all calls), calls per step
+            cps = max(1, len(d) // ev_steps)                         # calls per step
+            per_step = sorted(sum(d[i * cps:(i + 1) * cps]) for i in range(ev_steps))
+            kms[name] = (per_step[len(per_step) // 2], float(cps))   # median ms per step (all calls), calls per step
         # where in the step each native kernel runs: [first start, last end] in ms after the step's first launch
         timeline, t0e, per = {}, None, {}
         for name, phase, e in marks + [("step", 0, None)]:
