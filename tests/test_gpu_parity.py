@@ -318,3 +318,37 @@ def test_encoder_variants(built_lib, case, extra):
     zz = hip_pass()
     assert abs(float(zz.detach()) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
     _check_grads(model, P, rerun=hip_pass)
+
+
+@pytest.mark.parametrize("obj,T,N", [("PSVO", 2, 12), ("PSVO", 3, 130), ("PSVOwR", 2, 12), ("PSVOwR", 3, 33),
+                                     ("AESMC", 1, 9), ("IWAE", 2, 7), ("SVO", 2, 128)])
+def test_short_sequences(built_lib, obj, T, N):
+    """T = 1 .. 3: the first / last steps of the persistent kernels are special-cased (t = 0 proposal and filter
+    term, t = T-1 backward proposal, tile prefetch two steps ahead); values and gradients against the oracle."""
+    case = (obj, 2, T, N, 8, 2, 1, 32, True, True)
+    FLAGS, model, smc, obs, noise = _setup(*case, seed=11)
+    z_free, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
+    with torch.no_grad():
+        z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=Hh.noise_to_hip(noise, "cuda"))
+    assert abs(float(z) - float(z_free)) <= 1e-4 * abs(float(z_free))
+    assert torch.allclose(log["Xs"].double().cpu(), ref0["Xs"], atol=2e-4, rtol=1e-5)
+    teacher = {"idx_f": ref0["idx_f"]} if ref0["idx_f"] is not None else {}
+    if obj in ("PSVO", "PSVOwR"):
+        teacher["idx_b"] = ref0["idx_b"]
+    if obj == "PSVOwR":
+        teacher["idx_r"] = ref0["idx_r"]
+    z_ref, P = _oracle_grads(model, FLAGS, obj, obs, noise, teacher)
+    nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
+    for k, v in (("u_f", "idx_f"), ("u_b", "sel_b"), ("u_r", "anc_r")):
+        if v in nz:
+            nz.pop(k, None)
+
+    def hip_pass():
+        model.zero_grad()
+        zz, _ = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
+        zz.backward()
+        torch.cuda.synchronize()
+        return zz
+    zz = hip_pass()
+    assert abs(float(zz.detach()) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+    _check_grads(model, P, rerun=hip_pass)
