@@ -117,8 +117,11 @@ def test_adam_matches_tf_formula(built_lib):
     assert lin.weight.data_ptr() == flat.flat.data_ptr()
 
 
-def test_trainer_improves_elbo(built_lib, tmp_path, monkeypatch):
-    """a few epochs of the mirrored trainer on a small FHN set: ELBO goes up, artefacts are written"""
+@pytest.mark.parametrize("hipgraph", ["1", "0"])
+def test_trainer_improves_elbo(built_lib, tmp_path, monkeypatch, hipgraph):
+    """a few epochs of the mirrored trainer on a small FHN set: ELBO goes up, artefacts are written
+    (local step replayed from a hipGraph, and issued eagerly)"""
+    monkeypatch.setenv("PSVO_HIPGRAPH", hipgraph)
     from oracle import psvo_oracle as O
     from psvo_amd.model import SSM
     from psvo_amd.SMC.PSVO import PSVO
@@ -141,6 +144,8 @@ def test_trainer_improves_elbo(built_lib, tmp_path, monkeypatch):
     assert os.path.exists(tr.epoch_data_DIR + "metric_4.p") and os.path.exists(tr.epoch_data_DIR + "trajectory_4.p")
     Xs = tr.evaluate(log["Xs"], tr.saving_feed_dict)
     assert Xs.shape == (4, 30, 16, 2)
+    graphs = tr.__dict__.get("_graphs", {})
+    assert (len(graphs) == 1 and all(g is not False for g in graphs.values())) if hipgraph == "1" else not graphs
 
 
 @pytest.mark.parametrize("obj", ["PSVO", "SVO"])
