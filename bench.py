@@ -237,22 +237,14 @@ def main():
     if use_graph:
         try:
             if args.mode == "train":
-                # Adam's bias-correction scalar depends on the step count: freeze it at its asymptote inside
-                # the captured launch (lr_t -> lr), which is what a long training run sees after ~5k steps
-                if world == 1:
-                    def whole():
-                        z = local_step()
-                        update()
-                        return z
-                    t_saved, opt.t = opt.t, 10 ** 6
-                    step = GraphedStep(whole, generators=[smc.generator])
-                else:
-                    g_local = GraphedStep(local_step, generators=[smc.generator])
+                # as in psvo_amd.trainer.train_step: the local part of the step is replayed, the gradient all-reduce
+                # and Adam (step count, learning rate) stay eager behind it
+                g_local = GraphedStep(local_step, generators=[smc.generator])
 
-                    def step():
-                        z = g_local()
-                        update()
-                        return z
+                def step():
+                    z = g_local()
+                    update()
+                    return z
             else:
                 step = GraphedStep(lambda: fwd_step().detach(), generators=[smc.generator])
         except Exception as exc:     # e.g. a kernel that cannot be captured (cooperative launches): issue eagerly
