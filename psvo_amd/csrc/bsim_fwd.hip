@@ -4,8 +4,9 @@
 // Work decomposition (MI355X).  The B*N backward chains never interact (PSVO.py:116-151); each
 // chain step draws M sub-particles and needs, for each, logsumexp_j over ALL N forward particles
 // of the transition log-density (the reference's (M, N, N, B) tile, PSVO.py:128-133).
-//   * workgroup = 256 lanes = 256/M chains of ONE sequence b, persistent over t = T-1 .. 0;
-//   * lane = (chain, sub-particle m): the lane owns proposal m (sampling, MLP_f, MLP_g);
+//   * workgroup = 256 lanes = 256/(M*HS) chains of ONE sequence b, persistent over t = T-1 .. 0;
+//   * lane = (chain, [half,] sub-particle m): the lane owns proposal m (sampling, MLP_f, MLP_g); with HS = 2 the two
+//     halves of a chain split the forward particles and the hidden units of every MLP (two waves per SIMD at C*);
 //   * the pair loop is register-blocked over the lane's QUAD: the four lanes of a quad hold four
 //     consecutive m; each lane walks the forward particles j = q, q+4, ... (q = quad lane) and
 //     evaluates all four m of its quad against each j, so one 16-byte LDS broadcast read feeds
@@ -13,8 +14,9 @@
 //   * the forward tile of step t-1 -- F'_j = MLP_f(X_{t-1}[j]) * r and W'_j = normalised log
 //     weight, both pre-scaled into the log2 domain -- is staged in LDS (N * 16 B; 2 KB at N=128),
 //     double-buffered, prefetched from HBM one step ahead.  The tile is never materialised.
-//   * pair arithmetic: v = W'_j - sum_d (x'_d - F'_jd)^2  (log2 domain), online log-sum-exp in
-//     chunks of four j.
+//   * pair arithmetic: v = W'_j - sum_d (x'_d - F'_jd)^2  (log2 domain) in packed f32 (two sub-particles per
+//     instruction); log-sum-exp in blocks of 16 tile entries: all v of a block and its maximum first, then one
+//     rescale of the running sums and the block's exponentials (the tile is padded with W' = -inf to whole blocks).
 #include "common.h"
 
 namespace psvo {

@@ -1,10 +1,10 @@
 """hipGraph capture of a whole training / evaluation step.
 
-One PSVO training step is ~150 launches (7 long persistent kernels plus the small hoisted-MLP,
-noise and reduction kernels around them); at C* the persistent kernels take ~7.7 ms and the
-gaps between the many small launches another ~1 ms when issued eagerly from Python.  Capturing
-the step once and replaying it removes the host from the loop (MI355X guide: "capture
-launch-bound inner loops in hipGraphs").  Every replay executes the same kernels on the same
+One PSVO training step is ~90 launches on two streams (7 long persistent kernels plus the small
+noise, reduction and weight-gradient kernels around them); the Python thread that issues them needs
+~2.7 ms per C* step and more than the GPU time of the small AESMC-sized steps.  Capturing the step
+once and replaying it removes the host from the loop (MI355X guide: "capture launch-bound inner
+loops in hipGraphs").  Every replay executes the same kernels on the same
 buffers with fresh random draws (the generators are registered with the graph, so their Philox
 offsets advance per replay)."""
 import torch
