@@ -134,6 +134,34 @@ def cpu_baseline(wl, P, obs_cpu, sample_T, threads, train):
                       "(materialises the (M,N,N,B) tile like the reference's TF graph), %.1f s" % (what, sample_T, T, dt)}
 
 
+def elbo_vs_oracle(wl, P, obs_cpu, sample_T, device, threads):
+    """ELBO and smoothed trajectories of the HIP path against the fp64 CPU oracle on identical inputs: the same
+    parameters (the snapshot taken before training), observations and injected noise, first `sample_T` time steps."""
+    from oracle import psvo_oracle as O
+    from psvo_amd.model import SSM
+    obj, B, T, N, Dx, Dy, M, H, Dh = wl
+    torch.set_num_threads(threads)
+    P64 = O.params_to(P, torch.float64)
+    fl = dict(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, use_bootstrap=True, use_2_q=True,
+              objective=obj)
+    obs_s = obs_cpu[:, :sample_T].contiguous().double()
+    noise = O.make_noise(fl, B, sample_T, seed=7, dtype=torch.float64)
+    with torch.no_grad():
+        z_ref, log_ref = O.OBJECTIVES[obj](P64, fl).get_log_ZSMC(obs_s, noise)
+    FLAGS, model, smc = build_objective(wl, device, seed=0)
+    model.load_reference_layout(P)
+    perm = {"eps_f": (0, 2, 3, 1), "u_f": (0, 2, 1), "eps_b": (0, 3, 4, 2, 1), "u_b": (0, 2, 1), "u_r": (0, 2, 1)}
+    nz = {k: noise[k].permute(*perm[k]).float().contiguous().to(device) for k in perm if k in noise}
+    with torch.no_grad():
+        z, log = smc.get_log_ZSMC(obs_s.float().to(device), None, noise=nz)
+    torch.cuda.synchronize()
+    return {"elbo_hip": float(z), "elbo_oracle": float(z_ref),
+            "rel_err": abs(float(z) - float(z_ref)) / abs(float(z_ref)),
+            "max_abs_trajectory_err": float((log["Xs"].double().cpu() - log_ref["Xs"]).abs().max()),
+            "sample": "first %d of %d time steps of the workload, identical parameters / observations / injected "
+                      "noise, fp64 PyTorch-CPU oracle vs fp32 HIP path (in-kernel multinomial draws)" % (sample_T, T)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,6 +397,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, P_ref, obs.cpu(), min(args.cpu_sample_T, T),
                                                min(args.cpu_threads, os.cpu_count() or 1), args.mode == "train")
+            out["elbo_vs_oracle"] = elbo_vs_oracle(wl, P_ref, obs.cpu(), min(20, T), device,
+                                                   min(args.cpu_threads, os.cpu_count() or 1))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
