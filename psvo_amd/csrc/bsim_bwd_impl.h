@@ -151,13 +151,15 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 
     // ---- constants ----------------------------------------------------------------------------
     const float kappa = sqrtf(0.5f * kLog2e);  // rho_d * sigma_d
-    float sf[DX], isf[DX], rp[DX], isg[DY];
+    float sf[DX], isf[DX], rp[DX], isfk[DX], isg[DY];
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
         sf[d] = a.sig_f[d];
         isf[d] = 1.f / sf[d];
         rp[d] = isf[d] * kappa;
+        isfk[d] = isf[d] / kappa;      // (divisions by loop constants are hoisted: an IEEE division is ~10 VALU instructions)
     }
+    const float ikap2 = 1.f / (kappa * kappa);
 #pragma unroll
     for (int e = 0; e < DY; ++e) isg[e] = 1.f / a.sig_g[e];
     float pc[DX], pic[DX], pi1[DX], pi2[DX];
@@ -168,10 +170,11 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         pic[d] = pi1[d] + pi2[d];
         pc[d] = 1.f / pic[d];
     }
-    float s_init[DX], i_isig[DX], im[DX], mi[DX];
+    float s_init[DX], is_init[DX], i_isig[DX], im[DX], mi[DX];
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
         s_init[d] = a.sig_init[d];
+        is_init[d] = 1.f / s_init[d];
         i_isig[d] = 1.f / a.isig[d];
         im[d] = a.imean[b * DX + d];
         mi[d] = a.minit[b * DX + d];
@@ -409,8 +412,8 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
                 // U, V cover this half's forward particles only: partial sums; the "-1" is counted once
-                dxt[d] -= dlam * Uo[d] * isf[d] / kappa;
-                acc[AC::kSf + d] += dlam * (Vo[d] / (kappa * kappa) - (h0 ? 1.f : 0.f)) * isf[d];
+                dxt[d] -= dlam * Uo[d] * isfk[d];
+                acc[AC::kSf + d] += dlam * (Vo[d] * ikap2 - (h0 ? 1.f : 0.f)) * isf[d];
             }
         } else {
             // t = 0: iota_m = LN(x~; imean, isig)   (reference PSVO.py:169-175)
@@ -526,7 +529,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                 outv[d] = dmu[d];
                 if (lead) {
                     a.dmu1[(tb * DX + d) * N + n] = 0.f;
-                    acc[AC::kSinit + d] += sce[d] + aw / s_init[d];
+                    acc[AC::kSinit + d] += sce[d] + aw * is_init[d];
                 }
             }
         }
@@ -560,7 +563,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                     s = 0.f;
                     for (int w = 0; w < nwv; ++w) s += col[w * NA * NP];
                 }
-                if (d < DX) a.dFm_part[((tbm * nblk + blk) * DX + d) * N + j] = s * isf[d] / kappa;
+                if (d < DX) a.dFm_part[((tbm * nblk + blk) * DX + d) * N + j] = s * isfk[d];
                 else a.dlogW_part[(tbm * nblk + blk) * N + j] = s;
             }
         }

@@ -260,14 +260,14 @@ template <int MASK>
 __device__ __forceinline__ float xor_lane(float v) {
     static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8 || MASK == 16 || MASK == 32, "xor_lane mask");
     if constexpr (MASK == 1) {
-        return dpp_mov<0xB1>(v, v);                      // quad_perm [1,0,3,2]
+        return dpp_mov<0xB1, 0xF, 0xF, true>(v, v);      // quad_perm [1,0,3,2]
     } else if constexpr (MASK == 2) {
-        return dpp_mov<0x4E>(v, v);                      // quad_perm [2,3,0,1]
+        return dpp_mov<0x4E, 0xF, 0xF, true>(v, v);      // quad_perm [2,3,0,1]
     } else if constexpr (MASK == 4) {
         float t = dpp_mov<0x104, 0xF, 0x5>(v, v);        // banks 0,2 <- lane + 4   (row_shl:4)
         return dpp_mov<0x114, 0xF, 0xA>(t, v);           // banks 1,3 <- lane - 4   (row_shr:4)
     } else if constexpr (MASK == 8) {
-        return dpp_mov<0x128>(v, v);                     // row_ror:8
+        return dpp_mov<0x128, 0xF, 0xF, true>(v, v);     // row_ror:8
     } else if constexpr (MASK == 16) {
         const unsigned u = __builtin_bit_cast(unsigned, v);
         const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);

@@ -142,12 +142,14 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
     MQ::load(wqi, a.q1inv, tid, NTB);
 
     const float kappa = sqrtf(0.5f * kLog2e);
-    float isf[DX], rp[DX], isg[DY];
+    float isf[DX], rp[DX], isfk[DX], isg[DY];
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
         isf[d] = 1.f / a.sig_f[d];
         rp[d] = isf[d] * kappa;
+        isfk[d] = isf[d] / kappa;
     }
+    const float ikap2 = 1.f / (kappa * kappa);
 #pragma unroll
     for (int e = 0; e < DY; ++e) isg[e] = 1.f / a.sig_g[e];
     float pc[DX], pic[DX], pi1[DX], pi2[DX];
@@ -349,8 +351,8 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                 }
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
-                    dxt[d] -= cg * Uo[d] * isf[d] / kappa;
-                    acc[AC::kSf + d] += cg * (Vo[d] / (kappa * kappa) - 1.f) * isf[d];
+                    dxt[d] -= cg * Uo[d] * isfk[d];
+                    acc[AC::kSf + d] += cg * (Vo[d] * ikap2 - 1.f) * isf[d];
                 }
             } else {
 #pragma unroll
@@ -457,7 +459,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                 const int d = i / N, j = i - d * N;
                 float s = 0.f;
                 for (int w = 0; w < nw; ++w) s += jacc[(w * NA + d) * NP + j];
-                if (d < DX) a.dFm_part[((tbm * K + kb) * DX + d) * N + j] = s * isf[d] / kappa;
+                if (d < DX) a.dFm_part[((tbm * K + kb) * DX + d) * N + j] = s * isfk[d];
                 else {
                     a.dlogW_part[(tbm * K + kb) * N + j] = s;
                     wsum += s;
