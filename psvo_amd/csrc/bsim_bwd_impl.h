@@ -79,6 +79,9 @@ __device__ __forceinline__ void read_slot(const float* p, float (&F)[DX], float&
 
 // One butterfly stage of the reduce-scatter over quads: the NN live entries are halved; the lane
 // keeps the half selected by its `bit` and adds the partner's (lane ^ mask) copy of that half.
+// (v_permlane{32,16}_swap of (lo, hi) would do a stage without the selects, but hipcc 7.2 maps both results of
+//  __builtin_amdgcn_permlane32_swap to the first register when the operands differ -- it emitted lo' + lo' -- so the
+//  builtin is only used with identical operands, in xor_lane.)
 template <int CH, int NA, int NN, int MASK>
 __device__ __forceinline__ void rs_stage(float (&A)[CH][NA], int bit) {
 #pragma unroll
@@ -296,7 +299,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         }
 #pragma unroll
         for (int k = 0; k < DY; ++k) y[k] = cur_in.y[k];
-        const float pi_m = valid ? expf(cur_in.om) : 0.f;
+        const float pi_m = valid ? exp2_fast(cur_in.om * kLog2e) : 0.f;
         const float issel = (m == sel) ? 1.f : 0.f;
         const float dphi = aw * pi_m;                 // = d g_m = d iota_m
         const float dlam = -aw * (issel - pi_m);

@@ -391,10 +391,10 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         // ---- omega, normalise over the M sub-particles, draw one ---------------------------------------
         const float om_raw = lam + phi + g_lp - q_lp;
         const float omx = group_max<M>(om_raw);
-        const float pw = expf(om_raw - omx);
+        const float pw = exp2_fast((om_raw - omx) * kLog2e);
         const float cdfv = group_incl_scan<M>(pw, m);  // inclusive scan across the chain's M lanes
         const float total = __shfl(cdfv, gbase + M - 1);
-        const float omega = om_raw - (omx + logf(total));
+        const float omega = om_raw - fmaf(kLn2, log2_fast(total), omx);
         if (a.om_all && valid && hpart == 0) a.om_all[(tb * N + n) * M + m] = omega;
         int sel;
         if (a.sel_in) {

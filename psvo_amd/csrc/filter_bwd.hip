@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
             mu[d] = a.two_q ? K.c[d] * fmaf(K.i1[d], mean1[d], K.i2[d] * m2[d]) : mean1[d];
 
         // ---- gradient w.r.t. logW_t[n] ------------------------------------------------------------
-        const float sm = valid ? expf(c_sc[0] - c_sc[1]) : 0.f;
+        const float sm = valid ? exp2_fast((c_sc[0] - c_sc[1]) * kLog2e) : 0.f;
         float dlw = c_sc[2] * sm + c_sc[3];
         if (!a.resample) {
             const float tot = block_sum(dlnw, red, wave, lane, nw);
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
             mu[d] = a.two_q ? K.c[d] * fmaf(K.i1[d], mean1[d], K.i2[d] * m2[d]) : mean1[d];
 
         // ---- gradient w.r.t. logW_t[n] (the same in the four lanes of the particle) ---------------------------------
-        const float sm = valid ? expf(c_sc[0] - c_sc[1]) : 0.f;
+        const float sm = valid ? exp2_fast((c_sc[0] - c_sc[1]) * kLog2e) : 0.f;
         float dlw = c_sc[2] * sm + c_sc[3];
         if (!a.resample) {
             const float tot = block_sum(one ? dlnw : 0.f, red, wave, lane, nw);

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
         SEC(4);   // MLP_q1 (/ MLP_f), history stores
         // ---- log-sum-exp over particles and multinomial ancestors (SVO.py:266-300) -------------
         const float mx = block_max(lw, red, 0, wave, lane, nw);
-        const float w = valid ? expf(lw - mx) : 0.f;
+        const float w = valid ? exp2_fast((lw - mx) * kLog2e) : 0.f;
         float sc = wave_incl_scan(w, lane);
         float total;
         if (nw > 1) {
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
         } else {
             total = lane_bcast(sc, 63);
         }
-        const float lse_t = mx + logf(total);
+        const float lse_t = fmaf(kLn2, log2_fast(total), mx);
         if (tid == 0) a.lse[tb] = lse_t;
 
         SEC(5);   // block max, exp, scan, total
