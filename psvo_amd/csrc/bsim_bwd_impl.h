@@ -270,10 +270,14 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
     const int e0 = hpart * nqh, e1 = e0 + nqh;
 
     SEC_INIT(bsim_bwd)
-    for (int t = 0; t < T; ++t) {
+    // With one wave per SIMD (HS = 1) the first (t = 0: prior term instead of the tile pass) and last (t = T-1: no
+    // successor) steps are peeled out of the loop as separate instantiations of the step body, so that the T-2 steps in
+    // between carry no first / last branches (-15 % VALU instructions per step; C4 / C5 +3 %).  The half-split kernel
+    // (HS = 2, two waves per SIMD) measured SLOWER peeled (1.59 -> 1.87 ms at C*) and keeps the plain loop.
+    auto step = [&](auto first_tag, auto last_tag, const int t) {
         SEC(0);
         const size_t tb = (size_t)t * B + b;
-        const bool last = (t == T - 1), first = (t == 0);
+        const bool first = first_tag, last = last_tag;     // compile-time constants when the step is peeled
         const float* cur = tile + ((t + 1) & 1) * NP * PS;  // tile(t-1), valid for t >= 1
         float* nxt = tile + (t & 1) * NP * PS;              // tile(t) for step t+1
         if (t + 1 < T && t >= 1) stage_load(t);             // (tile(0) was staged in the prologue)
@@ -582,6 +586,13 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         cur_in = nxt_in;
         __syncthreads();
         SEC(8);   // tile store + barrier
+    };
+    if constexpr (HS == 1) {
+        step(std::true_type{}, std::false_type{}, 0);
+        for (int t = 1; t < T - 1; ++t) step(std::false_type{}, std::false_type{}, t);
+        step(std::false_type{}, std::true_type{}, T - 1);
+    } else {
+        for (int t = 0; t < T; ++t) step(t == 0, t == T - 1, t);
     }
 
     // ---- scalar accumulators: reduce over the workgroup ---------------------------------------------------------------
