@@ -495,9 +495,10 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
     load_step(T - 1, c_anc, c_x, c_e, c_m2, c_y, c_mean1, c_fmean, c_dfm, c_sc);
     __syncthreads();
 
-    for (int t = T - 1; t >= 0; --t) {
+    // t = 0 (own step constants, block sums instead of the scatter) is peeled out of the loop: see filter_fwd_lpp_kernel
+    auto step = [&](auto first_tag, const int t) {
         const size_t tb = (size_t)t * B + b;
-        const bool first = (t == 0);
+        constexpr bool first = decltype(first_tag)::value;
         const BStepK<DX> K = first ? K0 : K1;
         float inc[AC::kSet];
 #pragma unroll
@@ -667,7 +668,9 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
             acc[AC::kSet + i] += (!first && p == 0) ? inc[i] : 0.f;
         }
         __syncthreads();
-    }
+    };
+    for (int t = T - 1; t >= 1; --t) step(std::false_type{}, t);
+    step(std::true_type{}, 0);
 
 #pragma unroll
     for (int i = 0; i < AC::kN; ++i) {

@@ -378,10 +378,12 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
     __syncthreads();  // weights visible
 
     SEC_INIT(filter_fwd)
-    for (int t = 0; t < T; ++t) {
+    // t = 0 (its own proposal constants) is peeled: the loop proper then carries one set of step constants
+    // instead of selecting between two every step (scalar-register pressure: spills cost v_readlane + s_nop)
+    auto step = [&](auto first_tag, const int t) {
         SEC(0);
         const size_t tb = (size_t)t * B + b;
-        const StepK<DX> K = (t == 0) ? K0 : K1;
+        const StepK<DX> K = decltype(first_tag)::value ? K0 : K1;
         float eps_n[DX], mu2_n[DX], obs_n[DY], u_n = 0.f;
         int idx_n = 0;
         if (t + 1 < T) load_inputs(t + 1, eps_n, mu2_n, obs_n, u_n, idx_n);
@@ -539,7 +541,9 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         for (int k = 0; k < DY; ++k) obs_c[k] = obs_n[k];
         u_c = u_n;
         idx_c = idx_n;
-    }
+    };
+    step(std::true_type{}, 0);
+    for (int t = 1; t < T; ++t) step(std::false_type{}, t);
 }
 
 template <int DX, int DY, int H>
