@@ -330,20 +330,20 @@ def main():
             per_step = sorted(sum(d[i * cps:(i + 1) * cps]) for i in range(ev_steps))
             kms[name] = (per_step[len(per_step) // 2], float(cps))   # median ms per step (all calls), calls per step
         # where in the step each native kernel runs: [first start, last end] in ms after the step's first launch
-        timeline, t0e, per = {}, None, {}
+        tl_steps, t0e, per = {}, None, {}
         for name, phase, e in marks + [("step", 0, None)]:
             if name == "step":
                 if t0e is not None:
                     for k, (a0, a1) in per.items():
-                        tl = timeline.setdefault(k, [0.0, 0.0])
-                        tl[0] += t0e.elapsed_time(a0) / ev_steps
-                        tl[1] += t0e.elapsed_time(a1) / ev_steps
+                        tl_steps.setdefault(k, []).append((t0e.elapsed_time(a0), t0e.elapsed_time(a1)))
                 t0e, per = e, {}
             elif phase == 0:
                 per.setdefault(name, [e, e])
             else:
                 per[name][1] = e
-        timeline = {k: [round(v[0], 3), round(v[1], 3)] for k, v in sorted(timeline.items(), key=lambda kv: kv[1][0])}
+        med = lambda v: sorted(v)[len(v) // 2]
+        timeline = {k: [round(med([x[0] for x in v]), 3), round(med([x[1] for x in v]), 3)] for k, v in tl_steps.items()}
+        timeline = dict(sorted(timeline.items(), key=lambda kv: kv[1][0]))      # (medians over the instrumented steps)
         if os.environ.get("PSVO_BENCH_CALLS"):      # every native call of the last instrumented step, in issue order
             last = max(i for i, m in enumerate(marks) if m[0] == "step")
             t0c, calls, open_ = marks[last][2], [], {}

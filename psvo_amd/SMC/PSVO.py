@@ -32,7 +32,11 @@ class PSVO(SVO):
         log = {}
         # the filter (one workgroup per sequence) is issued on a side stream and overlaps with the encoder,
         # the backward-proposal means and the noise draws; events order it against the backward simulation
-        self._ov = Overlap(side_stream(obs.device)) if (autograd.OVERLAP and obs.is_cuda) else None
+        # (second side stream for the bsim weight gradients only in the default wiring: otherwise the hoisted
+        #  f.mean(mu_0) of the t = 0 term accumulates into the same gradient slice on the main stream)
+        both = self.model.use_bootstrap and self.model.use_2_q
+        self._ov = (Overlap(side_stream(obs.device), side_stream(obs.device, 1) if both else None)
+                    if (autograd.OVERLAP and obs.is_cuda) else None)
         self._sigmas = self.model.sigmas()          # every scale vector of this evaluation, one fused launch
         filt = self.SMC(hidden, obs, noise=noise)                      # pre-resampling X and log_Ws
         bs = self.backward_simulation_w_proposal(filt, obs, noise=noise)

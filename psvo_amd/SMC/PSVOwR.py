@@ -22,7 +22,11 @@ class PSVOwR(PSVO):
         self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
 
         log = {}
-        self._ov = Overlap(side_stream(obs.device)) if (autograd.OVERLAP and obs.is_cuda) else None
+        # (second side stream for the bsim weight gradients only in the default wiring: otherwise the hoisted
+        #  f.mean(mu_0) of the t = 0 term accumulates into the same gradient slice on the main stream)
+        both = self.model.use_bootstrap and self.model.use_2_q
+        self._ov = (Overlap(side_stream(obs.device), side_stream(obs.device, 1) if both else None)
+                    if (autograd.OVERLAP and obs.is_cuda) else None)
         self._sigmas = self.model.sigmas()
         filt = self.SMC(hidden, obs, noise=noise)
         bs = self.backward_simulation_w_resampling(filt, obs, noise=noise)

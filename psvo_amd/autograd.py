@@ -15,8 +15,9 @@ from . import ops
 # Stream overlap.  The filter kernels run one workgroup per sequence (32 of 256 CUs at C*), so they
 # are issued on a side stream and overlap with work that does not depend on them:
 #   forward : filter  ||  bsim noise draws, observation encoder, hoisted backward-proposal means
-#   backward: filter reverse pass + its weight gradients  ||  weight gradients of the bsim rows,
-#             hoisted-MLP backward, encoder BPTT
+#   backward: filter reverse pass + its weight gradients (side stream)  ||  weight gradients of the bsim rows
+#             (second side stream, when they accumulate straight into the flat gradient buffer)  ||  hoisted-MLP
+#             backward, encoder BPTT (main stream)
 # Synchronisation is by events only (never a device sync).
 # ---------------------------------------------------------------------------------------------
 _SIDE = {}
@@ -26,18 +27,19 @@ OVERLAP = True
 class Overlap(object):
     """events shared by the FilterFunction and BsimFunction nodes of ONE objective evaluation"""
 
-    def __init__(self, side):
+    def __init__(self, side, side2=None):
         self.side = side
+        self.side2 = side2                 # weight gradients of the backward-simulation rows (None: main stream)
         self.filter_done = None
         self.bsim_grads_ready = None
         self.bsim_wgrad_done = None
 
 
-def side_stream(device=None):
+def side_stream(device=None, which=0):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return _SIDE[dev]
+    if (dev, which) not in _SIDE:
+        _SIDE[(dev, which)] = torch.cuda.Stream(device=dev)
+    return _SIDE[(dev, which)]
 
 
 def _cf(t):
@@ -119,11 +121,15 @@ class FilterFunction(torch.autograd.Function):
                 # everything the main stream issued before this node accumulates into the same flat-gradient slices
                 # (bsim weight gradients: f, g; a hoisted f.mean(mu_0)): the filter's weight gradients go after it
                 side.wait_event(entered)
+                if ov.bsim_wgrad_done is not None:       # (recorded on the second side stream when used)
+                    side.wait_event(ov.bsim_wgrad_done)
             with ops.launch_on(side):
                 r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
                                         obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
                                         gbufs=ctx.gbufs, before_wgrad=before_wgrad)
             main.wait_stream(side)
+            if ov.bsim_wgrad_done is not None:
+                main.wait_event(ov.bsim_wgrad_done)
             _used_on(main, r.values())
         else:
             r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
@@ -178,12 +184,13 @@ class BsimFunction(torch.autograd.Function):
             if ov is not None:
                 ov.bsim_grads_ready = torch.cuda.Event()
                 ov.bsim_grads_ready.record()
+        ws = None if (ov is None or ctx.gbufs is None) else ov.side2
         r = ops.bsim_backward(desc, ctx.filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
                               imean, isig, obs_TB, eps_b, ctx.bs, _cg(dscore), gbufs=ctx.gbufs,
-                              after_kernel=after_kernel)
+                              after_kernel=after_kernel, wgrad_stream=ws)
         if ov is not None:
             ov.bsim_wgrad_done = torch.cuda.Event()
-            ov.bsim_wgrad_done.record()
+            ov.bsim_wgrad_done.record(ws if ws is not None else torch.cuda.current_stream())
         Dx, Dy, H = desc.Dx, desc.Dy, desc.H
         gb = ctx.gbufs or (None, None, None)
         none4 = (None,) * 4
@@ -233,12 +240,13 @@ class BsimWRFunction(torch.autograd.Function):
             if ov is not None:
                 ov.bsim_grads_ready = torch.cuda.Event()
                 ov.bsim_grads_ready.record()
+        ws = None if (ov is None or ctx.gbufs is None) else ov.side2
         r = ops.bsimwr_backward(desc, ctx.filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
                                 imean, isig, obs_TB, eps_b, ctx.bs, _cg(dlseW), gbufs=ctx.gbufs,
-                                after_kernel=after_kernel)
+                                after_kernel=after_kernel, wgrad_stream=ws)
         if ov is not None:
             ov.bsim_wgrad_done = torch.cuda.Event()
-            ov.bsim_wgrad_done.record()
+            ov.bsim_wgrad_done.record(ws if ws is not None else torch.cuda.current_stream())
         Dx, Dy, H = desc.Dx, desc.Dy, desc.H
         gb = ctx.gbufs or (None, None, None)
         none4 = (None,) * 4

@@ -44,6 +44,25 @@ class launch_on(object):
         return False
 
 
+class _wgrad_on(object):
+    """launch_on(stream), ordered after everything issued so far on the current stream; a no-op for None"""
+
+    def __init__(self, stream):
+        self.stream, self.ctx = stream, None
+
+    def __enter__(self):
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            self.ctx = launch_on(self.stream)
+            self.ctx.__enter__()
+        return self.stream
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -341,7 +360,7 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
 
 
 def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig,
-                  obs, eps_b, bs, dscore, gbufs=None, after_kernel=None):
+                  obs, eps_b, bs, dscore, gbufs=None, after_kernel=None, wgrad_stream=None):
     """psvo_bsim_backward + psvo_mlp_wgrad.  `bs` = bsim_forward(..., save=True) outputs."""
     lib = _lib.load()
     B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
@@ -381,10 +400,13 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
         after_kernel()
     # weight gradients from rows: MLP_f / MLP_g on the sub-particles, MLP_q1inv on bwX[t+1];
     # gbufs = (f, g, q1_inv) slices of the flat gradient buffer to accumulate into directly, or None
+    # wgrad_stream (only with gbufs: nothing is returned that the caller would read): issue the weight gradients on
+    # that stream, ordered after the kernel above, so that the caller's stream is free for what comes next
     gb = gbufs or (None, None, None)
-    out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx, grad=gb[0])
-    out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy, grad=gb[1])
-    out["gq1inv"] = mlp_wgrad(bs["bwX"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx, grad=gb[2])
+    with _wgrad_on(wgrad_stream if gbufs is not None else None):
+        out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx, grad=gb[0])
+        out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy, grad=gb[1])
+        out["gq1inv"] = mlp_wgrad(bs["bwX"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx, grad=gb[2])
     return out
 
 
@@ -430,7 +452,7 @@ def bsimwr_forward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, b
 
 
 def bsimwr_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig,
-                    obs, eps_b, bs, dlseW, gbufs=None, after_kernel=None):
+                    obs, eps_b, bs, dlseW, gbufs=None, after_kernel=None, wgrad_stream=None):
     """psvo_bsimwr_backward + psvo_mlp_wgrad.  `bs` = bsimwr_forward(..., save=True) outputs."""
     lib = _lib.load()
     B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
@@ -473,9 +495,10 @@ def bsimwr_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, 
     if after_kernel is not None:
         after_kernel()
     gb = gbufs or (None, None, None)
-    out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx, grad=gb[0])
-    out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy, grad=gb[1])
-    out["gq1inv"] = mlp_wgrad(bs["bwXanc"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx, grad=gb[2])
+    with _wgrad_on(wgrad_stream if gbufs is not None else None):
+        out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx, grad=gb[0])
+        out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy, grad=gb[1])
+        out["gq1inv"] = mlp_wgrad(bs["bwXanc"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx, grad=gb[2])
     return out
 
 
