@@ -118,9 +118,12 @@ class FilterFunction(torch.autograd.Function):
             entered.record(main)
 
             def before_wgrad():
-                # everything the main stream issued before this node accumulates into the same flat-gradient slices
-                # (bsim weight gradients: f, g; a hoisted f.mean(mu_0)): the filter's weight gradients go after it
-                side.wait_event(entered)
+                # other writers of the flat-gradient slices the filter's weight gradients accumulate into (q1 / f, g):
+                # the bsim weight gradients (event below) and, outside the default wiring, the hoisted f.mean(mu_0) on
+                # the main stream -- only then wait for everything the main stream issued before this node (with the
+                # second side stream in use there is no such writer, and waiting would serialise behind the encoder BPTT)
+                if ov.side2 is None:
+                    side.wait_event(entered)
                 if ov.bsim_wgrad_done is not None:       # (recorded on the second side stream when used)
                     side.wait_event(ov.bsim_wgrad_done)
             with ops.launch_on(side):
