@@ -360,6 +360,13 @@ int psvo_selftest_lanes(const float* in64, float* out576, void* stream);
 int psvo_elbo_filter(const psvo_desc* desc, const float* lse, float* out, void* stream);
 int psvo_elbo_bsim(const psvo_desc* desc, const float* score, float* out, void* stream);
 
+/* The PSVO training objective in one launch and its reverse: out[0] = mean_b psvo_elbo_bsim[b]
+ * (PSVO.py:52-67 including the reduce_mean), dscore[b,n] = dz[0] / B * softmax_n(score[b,:]).
+ * B is the local batch: a batch shard differentiates its own mean and the gradient all-reduce averages the shards. */
+int psvo_elbo_bsim_mean(const psvo_desc* desc, const float* score, float* out, void* stream);
+int psvo_elbo_bsim_mean_backward(const psvo_desc* desc, const float* score, const float* dz, float* dscore,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ import torch
 
 from .. import ops
 from .. import autograd
-from ..autograd import BsimFunction, Overlap, side_stream
+from ..autograd import BsimFunction, ElboBsimFunction, Overlap, side_stream
 from .SVO import SVO
 
 
@@ -48,9 +48,7 @@ class PSVO(SVO):
 
     def compute_log_ZSMC_bsim(self, score):
         """PSVO.py:52-67: mean_b [ logsumexp_n( sum_t(f+g) - sum_t Omega ) - log N ]."""
-        if score.requires_grad:
-            return (torch.logsumexp(score, dim=1) - math.log(float(score.shape[1]))).mean()
-        return ops.elbo_bsim(self._desc(self.n_particles_for_BSim_proposal), score).mean()
+        return ElboBsimFunction.apply(self._desc(self.n_particles_for_BSim_proposal), score)
 
     def backward_simulation_w_proposal(self, filt, obs, noise=None):
         model = self.model

@@ -67,6 +67,8 @@ SIGNATURES = {
     "psvo_selftest_lanes": (ctypes.c_int, [_P, _P, _P]),
     "psvo_elbo_filter": (ctypes.c_int, [_DESC, _P, _P, _P]),
     "psvo_elbo_bsim": (ctypes.c_int, [_DESC, _P, _P, _P]),
+    "psvo_elbo_bsim_mean": (ctypes.c_int, [_DESC, _P, _P, _P]),
+    "psvo_elbo_bsim_mean_backward": (ctypes.c_int, [_DESC, _P, _P, _P, _P]),
 }
 
 _lib = None

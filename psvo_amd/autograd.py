@@ -286,6 +286,21 @@ class RowsMLPFunction(torch.autograd.Function):
         return (None, dX) + tuple(ops.split_mlp_grad(g, Din, H, Dout))
 
 
+class ElboBsimFunction(torch.autograd.Function):
+    """psvo_elbo_bsim_mean / psvo_elbo_bsim_mean_backward: mean_b [logsumexp_n score - log N] (PSVO.py:52-67)
+    as one launch each way instead of torch's logsumexp/mean chain between the two bsim kernels."""
+
+    @staticmethod
+    def forward(ctx, desc, score):
+        score = _cf(score)
+        ctx.desc, ctx.score = desc, score
+        return ops.elbo_bsim_mean(desc, score)
+
+    @staticmethod
+    def backward(ctx, dz):
+        return None, ops.elbo_bsim_mean_backward(ctx.desc, ctx.score, dz)
+
+
 class BiLSTMFunction(torch.autograd.Function):
     """psvo_bilstm_forward / psvo_bilstm_backward: one bidirectional LSTMBlockCell layer."""
 

@@ -25,6 +25,43 @@ __global__ void elbo_bsim_kernel(const float* __restrict__ score, float* __restr
     if (threadIdx.x == 0) out[b] = mx + logf(s) - logf((float)N);
 }
 
+// out[0] = mean_b [ logsumexp_n score[b, n] - log N ]: the training objective in one launch
+// (one workgroup of 4 waves, sequences strided over the waves, fixed summation order)
+__global__ void __launch_bounds__(256) elbo_bsim_mean_kernel(const float* __restrict__ score, float* __restrict__ out,
+                                                             int B, int N) {
+    __shared__ float part[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float ninf = -__builtin_huge_valf();
+    float acc = 0.f;
+    for (int b = wave; b < B; b += 4) {
+        float mx = ninf;
+        for (int n = lane; n < N; n += 64) mx = fmaxf(mx, score[(size_t)b * N + n]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int n = lane; n < N; n += 64) s += expf(score[(size_t)b * N + n] - mx);
+        s = wave_sum(s);
+        acc += mx + logf(s);
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (part[0] + part[1] + part[2] + part[3]) / (float)B - logf((float)N);
+}
+
+// dscore[b, n] = dz[0] / B * softmax_n(score[b, :])   (reverse of elbo_bsim_mean_kernel)
+__global__ void elbo_bsim_mean_bwd_kernel(const float* __restrict__ score, const float* __restrict__ dz,
+                                          float* __restrict__ dscore, int B, int N) {
+    const int b = blockIdx.x;
+    const float ninf = -__builtin_huge_valf();
+    float mx = ninf;
+    for (int n = threadIdx.x; n < N; n += 64) mx = fmaxf(mx, score[(size_t)b * N + n]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += 64) s += expf(score[(size_t)b * N + n] - mx);
+    s = wave_sum(s);
+    const float a = dz[0] / ((float)B * s);
+    for (int n = threadIdx.x; n < N; n += 64) dscore[(size_t)b * N + n] = a * expf(score[(size_t)b * N + n] - mx);
+}
+
 }  // namespace psvo
 
 namespace psvo {
@@ -58,6 +95,23 @@ extern "C" int psvo_elbo_bsim(const psvo_desc* desc, const float* score, float* 
     psvo::clear_hip_error();
     hipLaunchKernelGGL(psvo::elbo_bsim_kernel, dim3(desc->B), dim3(64), 0, static_cast<hipStream_t>(stream), score,
                        out, desc->N);
+    return psvo::launch_status();
+}
+
+extern "C" int psvo_elbo_bsim_mean(const psvo_desc* desc, const float* score, float* out, void* stream) {
+    if (!desc || !score || !out || desc->B <= 0 || desc->N <= 0) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
+    hipLaunchKernelGGL(psvo::elbo_bsim_mean_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), score,
+                       out, desc->B, desc->N);
+    return psvo::launch_status();
+}
+
+extern "C" int psvo_elbo_bsim_mean_backward(const psvo_desc* desc, const float* score, const float* dz,
+                                            float* dscore, void* stream) {
+    if (!desc || !score || !dz || !dscore || desc->B <= 0 || desc->N <= 0) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
+    hipLaunchKernelGGL(psvo::elbo_bsim_mean_bwd_kernel, dim3(desc->B), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       score, dz, dscore, desc->B, desc->N);
     return psvo::launch_status();
 }
 

@@ -226,6 +226,25 @@ def elbo_bsim(desc, score):
     return out
 
 
+def elbo_bsim_mean(desc, score):
+    """psvo_elbo_bsim_mean: scalar mean_b [logsumexp_n score - log N] (0-d tensor)."""
+    lib = _lib.load()
+    _chk(score, (desc.B, desc.N), "score")
+    out = _empty(1, device=score.device)
+    _lib.check(lib.psvo_elbo_bsim_mean(ctypes.byref(desc), _ptr(score), _ptr(out), _stream()), "psvo_elbo_bsim_mean")
+    return out.reshape(())
+
+
+def elbo_bsim_mean_backward(desc, score, dz):
+    lib = _lib.load()
+    _chk(score, (desc.B, desc.N), "score")
+    dz = dz.detach().float().contiguous().reshape(1)
+    dscore = _empty(desc.B, desc.N, device=score.device)
+    _lib.check(lib.psvo_elbo_bsim_mean_backward(ctypes.byref(desc), _ptr(score), _ptr(dz), _ptr(dscore), _stream()),
+               "psvo_elbo_bsim_mean_backward")
+    return dscore
+
+
 def bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=False):
     """psvo_bilstm_forward: x (B,T,Din) -> out (B,T,2Dh) [, cs (2,B,T,Dh), gates (2,B,T,4Dh)]."""
     lib = _lib.load()
