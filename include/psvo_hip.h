@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PSVO_ABI_VERSION 1
+#define PSVO_ABI_VERSION 2
 
 typedef enum {
     PSVO_OK = 0,
@@ -58,6 +58,10 @@ typedef struct {
     int32_t resample;   /* 1: multinomial resampling every step (SVO/AESMC/PSVO); 0: IWAE      */
     int32_t two_q;      /* FLAGS.use_2_q                                                       */
     int32_t bootstrap;  /* FLAGS.use_bootstrap (f shares q1's MLP and sigma)                   */
+    int32_t emission;   /* 0: g = N(MLP_g(x), sig_g) (tf_mvn).  1: FLAGS.poisson_emission -- the
+                           reference's tf_poisson (src/distribution/poisson.py:27-50) is a UNIT-scale
+                           normal whose mean is softplus(MLP_g(x)) + 1e-6: pass sig_g = ones; the
+                           dsig_g output is then meaningless                                    */
 } psvo_desc;
 
 /* One-hidden-layer MLP, keras Dense layout (reference src/transformation/MLP.py:27-46):

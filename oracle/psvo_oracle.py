@@ -83,6 +83,23 @@ class OracleMVN:
         return x, diag_log_prob(x, mu, s)
 
 
+class OraclePoisson:
+    """tf_poisson -- src/distribution/poisson.py:27-50.  The reference builds MultivariateNormalDiag(lambdas) with
+    lambdas = softplus(MLP(Input)) + 1e-6 and no scale (:33-38): a unit-scale normal, emission only."""
+
+    def __init__(self, p):
+        self.p = p
+
+    def mean(self, Input):                       # poisson.py:45-48
+        return torch.nn.functional.softplus(mlp_transform(self.p, Input)) + 1e-6
+
+    def sigma(self):
+        return torch.ones_like(self.p["mu"][1])
+
+    def log_prob(self, Input, output):           # poisson.py:40-43
+        return diag_log_prob(output, self.mean(Input), self.sigma())
+
+
 def logsumexp(x, dim, keepdim=False):
     return torch.logsumexp(x, dim=dim, keepdim=keepdim)
 
@@ -196,7 +213,7 @@ class OracleSVO:
         self.q1 = OracleMVN(params["q1"])
         self.q2 = OracleMVN(params["q2"]) if flags["use_2_q"] else None
         self.f = self.q1 if flags["use_bootstrap"] else OracleMVN(params["f"])   # src/model.py:145-151
-        self.g = OracleMVN(params["g"])
+        self.g = (OraclePoisson if flags.get("poisson_emission", False) else OracleMVN)(params["g"])   # model.py:153-160
         self.use_bootstrap = flags["use_bootstrap"]
         self.use_2_q = flags["use_2_q"]
         self.n_particles = flags["n_particles"]

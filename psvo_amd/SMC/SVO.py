@@ -63,7 +63,9 @@ class SVO:
 
     def _sigma(self, dist):
         sig = getattr(self, "_sigmas", None)
-        return dist.get_sigma() if sig is None else sig[id(dist)]
+        if sig is None or id(dist) not in sig:      # (tf_poisson has no scale vector: constant ones)
+            return dist.get_sigma()
+        return sig[id(dist)]
 
     @staticmethod
     def _gbuf(tran):
@@ -73,7 +75,8 @@ class SVO:
     def _make_desc(self, M, H):
         return ops.make_desc(self.batch_size, self.time, self.n_particles, M, self.model.Dx, self.model.Dy, H,
                              resample=self.resample_particles, two_q=self.model.use_2_q,
-                             bootstrap=self.model.use_bootstrap)
+                             bootstrap=self.model.use_bootstrap,
+                             emission=int(getattr(self.model, "poisson_emission", False)))
 
     def _randn(self, *shape, device):
         return torch.randn(*shape, device=device, dtype=torch.float32, generator=self.generator)

@@ -21,7 +21,7 @@ class PsvoHipError(RuntimeError):
 
 class psvo_desc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("B", "T", "N", "M", "Dx", "Dy", "H", "resample", "two_q", "bootstrap")]
+                ("B", "T", "N", "M", "Dx", "Dy", "H", "resample", "two_q", "bootstrap", "emission")]
 
 
 class psvo_mlp(ctypes.Structure):

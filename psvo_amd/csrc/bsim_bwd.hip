@@ -36,7 +36,7 @@ extern "C" int psvo_bsim_backward(
     if (desc->N > 1024 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
 
     BsimBwdArgs a;
-    a.B = desc->B; a.T = desc->T; a.N = desc->N;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N; a.emission = desc->emission;
     a.f = *f; a.g = *g; a.q1inv = *q1_inv;
     a.Fm = Fm; a.logW = logW; a.lse = lse;
     a.sig_f = sig_f; a.sig_g = sig_g; a.sig_q1inv = sig_q1inv; a.sig_bq2 = sig_bq2;

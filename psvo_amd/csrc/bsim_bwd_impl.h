@@ -29,7 +29,7 @@ PSVO_TIMERS_DEFINE(bsim_bwd)
 
 
 struct BsimBwdArgs {
-    int B, T, N;
+    int B, T, N, emission;
     psvo_mlp f, g, q1inv;
     const float *Fm, *logW, *lse;
     const float *sig_f, *sig_g, *sig_q1inv, *sig_bq2;
@@ -482,8 +482,10 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
             }
 #pragma unroll
             for (int k = 0; k < DY; ++k) {
+                float dmean = 1.f;
+                if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
                 const float z = (y[k] - gm[k]) * isg[k];
-                dGo[k] = dphi * z * isg[k];
+                dGo[k] = dphi * z * isg[k] * dmean;
                 if (h0) acc[AC::kSg + k] += dphi * (z * z - 1.f) * isg[k];
                 if (valid && h0) a.dGt[((tb * DY + k) * N + n) * M + m] = dGo[k];
             }

@@ -25,7 +25,7 @@ PSVO_TIMERS_DEFINE(bsim_fwd)
 
 struct BsimArgs {
     int B, T, N;
-    int two_q_unused;
+    int emission;
     psvo_mlp f, g, q1inv;
     const float *X, *Fm, *logW, *lse;
     const float *sig_f, *sig_g, *sig_q1inv, *sig_bq2;
@@ -280,6 +280,10 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
 #pragma unroll
             for (int k = 0; k < DY; ++k) gm[k] += xor_lane<M>(gm[k]);
         }
+        if (a.emission) {
+#pragma unroll
+            for (int k = 0; k < DY; ++k) gm[k] = emis_mean(gm[k]);
+        }
         const float g_lp = diag_lp<DY>(obs_c, gm, isg, kg);
 
         SEC(3);   // MLP_f, MLP_g, densities
@@ -533,7 +537,7 @@ extern "C" int psvo_bsim_forward(const psvo_desc* desc, const float* X, const fl
     (void)X;
 
     BsimArgs a;
-    a.B = desc->B; a.T = desc->T; a.N = desc->N; a.two_q_unused = 0;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N; a.emission = desc->emission;
     a.f = *f; a.g = *g; a.q1inv = *q1_inv;
     a.X = X; a.Fm = Fm; a.logW = logW; a.lse = lse;
     a.sig_f = sig_f; a.sig_g = sig_g; a.sig_q1inv = sig_q1inv; a.sig_bq2 = sig_bq2;

@@ -79,6 +79,11 @@ __device__ __forceinline__ f2 pk_max(f2 a, f2 b) { return __builtin_elementwise_
 // One-hidden-layer MLP with weights staged in LDS, read as wave-uniform float4 broadcasts.
 // LDS image: W1[DIN][H] | b1[H] | W2T[DOUT][H] | b2[DOUT padded to 4]
 // ---------------------------------------------------------------------------------------------
+// mean of the reference's tf_poisson emission (src/distribution/poisson.py:33-38): softplus(MLP_g(x)) + 1e-6 under a
+// unit-scale normal; emis_dmean is d mean / d MLP output (softplus threshold 20 as in psvo_sigma_forward)
+__device__ __forceinline__ float emis_mean(float r) { return (r > 20.f ? r : log1pf(expf(r))) + 1e-6f; }
+__device__ __forceinline__ float emis_dmean(float r) { return 1.f / (1.f + expf(-r)); }
+
 template <int DIN, int H, int DOUT>
 struct MlpLds {
     static constexpr int kW1 = 0;

@@ -21,7 +21,7 @@ PSVO_TIMERS_DEFINE(filter_bwd)
 
 struct FilterBwdArgs {
     int B, T, N;
-    int resample, two_q, bootstrap;
+    int resample, two_q, bootstrap, emission;
     psvo_mlp q1, f, g;
     const float *sig_q1, *sig_q2, *sig_f, *sig_g;
     const float *mu2, *m0, *sig0, *fm0, *fsig0, *obs, *eps;
@@ -257,8 +257,10 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
             MG::template eval<kRolled>(wg, x, gm);
 #pragma unroll
             for (int k = 0; k < DY; ++k) {
+                float dmean = 1.f;
+                if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
                 const float z = (y[k] - gm[k]) * isg[k];
-                dgm[k] = dlw * z * isg[k];
+                dgm[k] = dlw * z * isg[k] * dmean;
                 acc[AC::kSg + k] += dlw * (z * z - 1.f) * isg[k];
                 if (valid) a.dG[(tb * DY + k) * N + n] = dgm[k];
             }
@@ -553,8 +555,10 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
 #pragma unroll
             for (int k = 0; k < DY; ++k) {
                 gm[k] = group_sum<P>(gm[k]);
+                float dmean = 1.f;
+                if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
                 const float z = (y[k] - gm[k]) * isg[k];
-                dgm[k] = dlw * z * isg[k];
+                dgm[k] = dlw * z * isg[k] * dmean;
                 acc[AC::kSg + k] += cnt * dlw * (z * z - 1.f) * isg[k];
                 if (valid && p == 2) a.dG[(tb * DY + k) * N + n] = dgm[k];
             }
@@ -825,7 +829,7 @@ extern "C" int psvo_filter_backward(
 
     FilterBwdArgs a;
     a.B = desc->B; a.T = desc->T; a.N = desc->N;
-    a.resample = desc->resample; a.two_q = desc->two_q; a.bootstrap = desc->bootstrap;
+    a.resample = desc->resample; a.two_q = desc->two_q; a.bootstrap = desc->bootstrap; a.emission = desc->emission;
     a.q1 = *q1; a.f = desc->bootstrap ? *q1 : *f; a.g = *g;
     a.sig_q1 = sig_q1; a.sig_q2 = sig_q2; a.sig_f = sig_f; a.sig_g = sig_g;
     a.mu2 = mu2; a.m0 = m0; a.sig0 = sig0; a.fm0 = fm0; a.fsig0 = fsig0; a.obs = obs; a.eps = eps;

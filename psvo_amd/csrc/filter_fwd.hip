@@ -16,7 +16,7 @@ PSVO_TIMERS_DEFINE(filter_fwd)
 
 struct FilterArgs {
     int B, T, N;
-    int resample, two_q, bootstrap;
+    int resample, two_q, bootstrap, emission;
     psvo_mlp q1, f, g;
     const float *sig_q1, *sig_q2, *sig_f, *sig_g;
     const float *mu2, *m0, *sig0, *fm0, *fsig0, *obs, *eps, *u;
@@ -61,7 +61,9 @@ __device__ __forceinline__ StepK<DX> make_stepk(const float* s1, const float* s2
     return K;
 }
 
-template <int DX, int DY, int H, int MAXT>
+// EM: emission variant fixed at compile time (0 / 1) or read from the arguments (2).  The one-wave-per-SIMD build
+// (MAXT = 256) keeps every MLP weight in VGPRs only without the extra branch in its time loop, so it is compiled both ways.
+template <int DX, int DY, int H, int MAXT, int EM = 2>
 __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
@@ -173,6 +175,10 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
         // ---- emission ------------------------------------------------------------------------
         float gm[DY];
         MG::template eval<kOpaque>(wg_t, x, gm);
+        if (EM == 2 ? (a.emission != 0) : (EM == 1)) {
+#pragma unroll
+            for (int k = 0; k < DY; ++k) gm[k] = emis_mean(gm[k]);
+        }
         const float g_lp = diag_lp<DY>(obs_c, gm, isg, lg);
 
         float lw = f_lp + g_lp - q_lp + lnw;
@@ -411,6 +417,10 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         if (!a.bootstrap) MQ::template eval_part<P>(wfm + zo, p, x, fm);
 #pragma unroll
         for (int k = 0; k < DY; ++k) gm[k] = group_sum<P>(gm[k]);
+        if (a.emission) {
+#pragma unroll
+            for (int k = 0; k < DY; ++k) gm[k] = emis_mean(gm[k]);
+        }
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
             p1[d] = group_sum<P>(p1[d]);
@@ -568,8 +578,10 @@ static int launch_filter(const FilterArgs& a, hipStream_t stream) {
     clear_hip_error();
     // the register budget follows the workgroup size: <= 256 threads is one wave per SIMD, so
     // the compiler may keep every MLP weight resident in VGPRs
-    if (NT <= 256)
-        hipLaunchKernelGGL((filter_fwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, a);
+    if (NT <= 256 && a.emission)
+        hipLaunchKernelGGL((filter_fwd_kernel<DX, DY, H, 256, 1>), dim3(a.B), dim3(NT), lds, stream, a);
+    else if (NT <= 256)
+        hipLaunchKernelGGL((filter_fwd_kernel<DX, DY, H, 256, 0>), dim3(a.B), dim3(NT), lds, stream, a);
     else
         hipLaunchKernelGGL((filter_fwd_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT), lds, stream, a);
     return launch_status();
@@ -614,7 +626,7 @@ extern "C" int psvo_filter_forward(const psvo_desc* desc, const psvo_mlp* q1, co
 
     FilterArgs a;
     a.B = desc->B; a.T = desc->T; a.N = desc->N;
-    a.resample = desc->resample; a.two_q = desc->two_q; a.bootstrap = desc->bootstrap;
+    a.resample = desc->resample; a.two_q = desc->two_q; a.bootstrap = desc->bootstrap; a.emission = desc->emission;
     a.q1 = *q1; a.f = desc->bootstrap ? *q1 : *f; a.g = *g;
     a.sig_q1 = sig_q1; a.sig_q2 = sig_q2; a.sig_f = sig_f; a.sig_g = sig_g;
     a.mu2 = mu2; a.m0 = m0; a.sig0 = sig0; a.fm0 = fm0; a.fsig0 = fsig0;

@@ -18,7 +18,7 @@
 namespace psvo {
 
 struct WrBwdArgs {
-    int B, T, N;
+    int B, T, N, emission;
     psvo_mlp f, g, q1inv;
     const float *Fm, *logW, *lse;
     const float *sig_f, *sig_g, *sig_q1inv, *sig_bq2;
@@ -393,8 +393,10 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                 MG::template eval<kRolled>(wg, x, gm);
 #pragma unroll
                 for (int k = 0; k < DY; ++k) {
+                    float dmean = 1.f;
+                    if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
                     const float z = (y[k] - gm[k]) * isg[k];
-                    dGo[k] = cg * z * isg[k];
+                    dGo[k] = cg * z * isg[k] * dmean;
                     acc[AC::kSg + k] += cg * (z * z - 1.f) * isg[k];
                     if (valid) a.dGt[((tb * DY + k) * N + n) * M + m] = dGo[k];
                 }
@@ -623,7 +625,7 @@ extern "C" int psvo_bsimwr_backward(
     if (desc->B <= 0 || desc->T < 2 || desc->N <= 0 || desc->M <= 0) return PSVO_ERR_INVALID;
     if (desc->N > 1024 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
     WrBwdArgs a;
-    a.B = desc->B; a.T = desc->T; a.N = desc->N;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N; a.emission = desc->emission;
     a.f = *f; a.g = *g; a.q1inv = *q1_inv;
     a.Fm = Fm; a.logW = logW; a.lse = lse;
     a.sig_f = sig_f; a.sig_g = sig_g; a.sig_q1inv = sig_q1inv; a.sig_bq2 = sig_bq2;

@@ -18,7 +18,7 @@
 namespace psvo {
 
 struct WrArgs {
-    int B, T, N;
+    int B, T, N, emission;
     psvo_mlp f, g, q1inv;
     const float *Fm, *logW, *lse;
     const float *sig_f, *sig_g, *sig_q1inv, *sig_bq2;
@@ -248,6 +248,10 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
             }
             float gm[DY];
             MG::template eval<kRolled>(wg, x, gm);
+            if (a.emission) {
+#pragma unroll
+                for (int k = 0; k < DY; ++k) gm[k] = emis_mean(gm[k]);
+            }
             const float g_lp = diag_lp<DY>(y, gm, isg, kg);
 
             // ---- filter term over the LDS tile: quad register blocking, packed f32, block-wise log-sum-exp --------
@@ -507,7 +511,7 @@ extern "C" int psvo_bsimwr_forward(const psvo_desc* desc, const float* Fm, const
     if (desc->B <= 0 || desc->T < 2 || desc->N <= 0 || desc->M <= 0) return PSVO_ERR_INVALID;
     if (desc->N > 1024 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
     WrArgs a;
-    a.B = desc->B; a.T = desc->T; a.N = desc->N;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N; a.emission = desc->emission;
     a.f = *f; a.g = *g; a.q1inv = *q1_inv;
     a.Fm = Fm; a.logW = logW; a.lse = lse;
     a.sig_f = sig_f; a.sig_g = sig_g; a.sig_q1inv = sig_q1inv; a.sig_bq2 = sig_bq2;

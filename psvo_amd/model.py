@@ -8,6 +8,7 @@ import torch
 from torch import nn
 
 from .distribution.mvn import tf_mvn
+from .distribution.poisson import tf_poisson
 from .transformation.MLP import MLP_transformation
 
 
@@ -146,9 +147,6 @@ class SSM(nn.Module):
         self.PSVO, self.PSVOwR, self.SVO = FLAGS.PSVO, getattr(FLAGS, "PSVOwR", False), FLAGS.SVO
         self.BSim_use_single_RNN = FLAGS.BSim_use_single_RNN
 
-        if self.poisson_emission:
-            raise NotImplementedError("poisson_emission is outside the MI355X hot-path scope (SURVEY section 2 row 2)")
-
         # placeholders of the reference (model.py:63-65) have no equivalent; kept as feed keys
         self.obs, self.hidden = "obs", "hidden"
 
@@ -197,7 +195,10 @@ class SSM(nn.Module):
             self.f_dist = self.q1_dist
         else:
             self.f_dist = tf_mvn(self.f_tran, self.f_sigma_init, self.f_sigma_min, "f_dist")
-        self.g_dist = tf_mvn(self.g_tran, self.g_sigma_init, self.g_sigma_min, "g_dist")
+        if self.poisson_emission:                            # model.py:153-155
+            self.g_dist = tf_poisson(self.g_tran, "g_dist")
+        else:
+            self.g_dist = tf_mvn(self.g_tran, self.g_sigma_init, self.g_sigma_min, "g_dist")
 
     def init_RNNs(self):                                     # model.py:162-192
         if self.SVO or self.PSVO or self.PSVOwR:
@@ -241,9 +242,11 @@ class SSM(nn.Module):
 
         def dist(d):
             tr = d.transformation
-            return {"layers": [(cv(W), cv(b)) for W, b in zip(tr.kernels, tr.biases)],
-                    "mu": (cv(tr.mu_kernel), cv(tr.mu_bias)),
-                    "sigma_raw": cv(d.sigma_con), "sigma_min": float(d.sigma_min)}
+            out = {"layers": [(cv(W), cv(b)) for W, b in zip(tr.kernels, tr.biases)],
+                   "mu": (cv(tr.mu_kernel), cv(tr.mu_bias))}
+            if isinstance(d, tf_mvn):                        # (tf_poisson has no scale variable)
+                out.update({"sigma_raw": cv(d.sigma_con), "sigma_min": float(d.sigma_min)})
+            return out
 
         P = {"q0": dist(self.q0_dist), "q1": dist(self.q1_dist), "g": dist(self.g_dist)}
         if self.use_2_q:
@@ -278,8 +281,9 @@ class SSM(nn.Module):
             for (W, b), (Ws, bs) in zip(zip(tr.kernels, tr.biases), p["layers"]):
                 put(W, Ws); put(b, bs)
             put(tr.mu_kernel, p["mu"][0]); put(tr.mu_bias, p["mu"][1])
-            put(d.sigma_con, p["sigma_raw"])
-            d.sigma_min = float(p["sigma_min"])
+            if isinstance(d, tf_mvn):
+                put(d.sigma_con, p["sigma_raw"])
+                d.sigma_min = float(p["sigma_min"])
 
         dist(self.q0_dist, P["q0"]); dist(self.q1_dist, P["q1"]); dist(self.g_dist, P["g"])
         if self.use_2_q:

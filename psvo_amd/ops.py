@@ -99,10 +99,11 @@ def _mlp_struct(p, Din, H, Dout, name):
     return s
 
 
-def make_desc(B, T, N, M, Dx, Dy, H, resample=True, two_q=True, bootstrap=True):
+def make_desc(B, T, N, M, Dx, Dy, H, resample=True, two_q=True, bootstrap=True, emission=0):
     d = _lib.psvo_desc()
     d.B, d.T, d.N, d.M, d.Dx, d.Dy, d.H = B, T, N, M, Dx, Dy, H
     d.resample, d.two_q, d.bootstrap = int(resample), int(two_q), int(bootstrap)
+    d.emission = int(emission)        # 1: tf_poisson emission (unit-scale normal, softplus mean)
     return d
 
 

@@ -27,7 +27,10 @@ CASES = {
     "iwae_c1": ("IWAE", 1, 50, 4, 4, 2, 1, 32, 8, True, True),
     "svo_small": ("SVO", 2, 7, 16, 4, 2, 1, 16, 8, True, True),
     "psvowr_small": ("PSVOwR", 2, 6, 12, 4, 2, 1, 16, 8, True, True),
+    "psvo_poisson": ("PSVO", 2, 6, 12, 4, 2, 2, 16, 8, True, True),
 }
+# flags beyond the tuple (same names as the reference's FLAGS)
+EXTRA = {"psvo_poisson": dict(poisson_emission=True)}
 
 
 def flatten(prefix, x, out):
@@ -49,6 +52,7 @@ def build(name):
     obj, B, T, N, M, Dx, Dy, H, Dh, boot, two_q = CASES[name]
     fl = dict(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, use_bootstrap=boot, use_2_q=two_q,
               objective=obj, layers=[H], y_smoother_Dhs=[Dh], X0_smoother_Dhs=[Dh], sigma_init=1.3, sigma_min=0.5)
+    fl.update(EXTRA.get(name, {}))
     P = O.make_params(fl, seed=11, dtype=torch.float64, bias_scale=0.2)
     _, obs = O.fhn_synthetic(B, T, seed=3)
     if Dy != 1 or Dx != 2:

@@ -17,7 +17,8 @@ def oracle_flags(FLAGS, objective):
     return dict(Dx=FLAGS.Dx, Dy=FLAGS.Dy, n_particles=FLAGS.n_particles,
                 n_particles_for_BSim_proposal=FLAGS.n_particles_for_BSim_proposal,
                 use_bootstrap=FLAGS.use_bootstrap, use_2_q=FLAGS.use_2_q, objective=objective,
-                use_stack_rnn=FLAGS.use_stack_rnn, BSim_use_single_RNN=FLAGS.BSim_use_single_RNN)
+                use_stack_rnn=FLAGS.use_stack_rnn, BSim_use_single_RNN=FLAGS.BSim_use_single_RNN,
+                poisson_emission=FLAGS.poisson_emission)
 
 
 def noise_to_hip(noise, device):

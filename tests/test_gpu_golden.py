@@ -39,7 +39,8 @@ def test_golden_vectors(built_lib, name):
     hs = str(H)
     FLAGS = Hh.make_flags(obj, Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, batch_size=B, time=T,
                           q0_layers=hs, q1_layers=hs, q2_layers=hs, f_layers=hs, g_layers=hs,
-                          y_smoother_Dhs=str(Dh), X0_smoother_Dhs=str(Dh), use_bootstrap=boot, use_2_q=two_q)
+                          y_smoother_Dhs=str(Dh), X0_smoother_Dhs=str(Dh), use_bootstrap=boot, use_2_q=two_q,
+                          **MG.EXTRA.get(name, {}))
     model = SSM(FLAGS).load_reference_layout(P).cuda()
     smc = _objective(obj)(model, FLAGS)
     z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=Hh.noise_to_hip(noise, "cuda"))

@@ -53,6 +53,19 @@ ENCODER_CASES = [
 ]
 
 
+# FLAGS.poisson_emission (reference src/model.py:153-155, src/distribution/poisson.py:27-50): every kernel family,
+# both filter kernels (four lanes per particle at N <= 128 / one lane per particle) and the split-hidden bsim kernels
+EMISSION_CASES = [
+    (("AESMC", 2, 6, 16, 1, 2, 1, 32, True, True), dict(poisson_emission=True)),
+    (("SVO", 2, 5, 160, 1, 3, 2, 16, False, True), dict(poisson_emission=True)),
+    (("IWAE", 2, 5, 12, 1, 2, 1, 16, True, False), dict(poisson_emission=True)),
+    (("PSVO", 2, 6, 16, 8, 2, 1, 32, True, True), dict(poisson_emission=True)),
+    (("PSVO", 2, 5, 40, 4, 3, 2, 16, False, False), dict(poisson_emission=True)),
+    (("PSVO", 1, 4, 130, 16, 2, 1, 64, True, True), dict(poisson_emission=True)),
+    (("PSVOwR", 2, 5, 12, 4, 2, 1, 16, True, True), dict(poisson_emission=True)),
+]
+
+
 def _setup(obj, B, T, N, M, Dx, Dy, H, bootstrap, two_q, seed=0, **extra):
     from psvo_amd.model import SSM
     from psvo_amd.SMC.SVO import SVO
@@ -188,7 +201,8 @@ def _pairs(model, P):
             out.append((name + ".b%d" % i, b, P[name]["layers"][i][1]))
         out.append((name + ".Wmu", tr.mu_kernel, P[name]["mu"][0]))
         out.append((name + ".bmu", tr.mu_bias, P[name]["mu"][1]))
-        out.append((name + ".sigma", d.sigma_con, P[name]["sigma_raw"]))
+        if "sigma_raw" in P[name]:                  # (tf_poisson has no scale variable)
+            out.append((name + ".sigma", d.sigma_con, P[name]["sigma_raw"]))
     dist("q0", model.q0_dist); dist("q1", model.q1_dist); dist("g", model.g_dist)
     if model.use_2_q:
         dist("q2", model.q2_dist)
@@ -287,11 +301,11 @@ def test_cross_lane_primitives(built_lib):
     assert torch.equal(out[8], x.max().expand(64))
 
 
-@pytest.mark.parametrize("case,extra", ENCODER_CASES, ids=lambda c: "-".join(map(str, c)) if isinstance(c, tuple) else
+@pytest.mark.parametrize("case,extra", ENCODER_CASES + EMISSION_CASES, ids=lambda c: "-".join(map(str, c)) if isinstance(c, tuple) else
                          ",".join("%s=%s" % kv for kv in c.items()))
 def test_encoder_variants(built_lib, case, extra):
-    """use_stack_rnn=False (two MultiRNNCells) and BSim_use_single_RNN (forward cells only): values, indices and
-    every gradient against the oracle."""
+    """use_stack_rnn=False (two MultiRNNCells), BSim_use_single_RNN (forward cells only) and poisson_emission
+    (psvo_desc.emission = 1): values, indices and every gradient against the oracle."""
     obj = case[0]
     FLAGS, model, smc, obs, noise = _setup(*case, seed=7, **extra)
     z_free, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
@@ -299,7 +313,7 @@ def test_encoder_variants(built_lib, case, extra):
         z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=Hh.noise_to_hip(noise, "cuda"))
     assert abs(float(z) - float(z_free)) <= 1e-4 * abs(float(z_free))
     assert torch.allclose(log["Xs"].double().cpu(), ref0["Xs"], atol=2e-4, rtol=1e-5)
-    teacher = {"idx_f": ref0["idx_f"]}
+    teacher = {"idx_f": ref0["idx_f"]} if ref0["idx_f"] is not None else {}
     if obj in ("PSVO", "PSVOwR"):
         teacher["idx_b"] = ref0["idx_b"]
     if obj == "PSVOwR":

@@ -1,6 +1,7 @@
 """CPU tests of the host-side mirror: flag registry, SSM inventory / sharing, encoder and k-step
 prediction against the oracle, data loading / generation, R-square, and the refusal to run the
 hot path without a GPU (no CPU fallback)."""
+import math
 import pickle
 
 import numpy as np
@@ -40,8 +41,31 @@ def test_ssm_inventory_and_sharing():
     assert tuple(m2.X0_transformer_kernel.shape) == (128, 2)
     with pytest.raises(ValueError):
         SSM(Hh.make_flags("AESMC", q1_layers="32,32")).q1_tran.hip_params()
-    with pytest.raises(NotImplementedError):
-        SSM(Hh.make_flags("AESMC", poisson_emission=True))
+
+
+def test_poisson_emission_mirror_matches_oracle_on_cpu():
+    """FLAGS.poisson_emission: g_dist is the reference's tf_poisson (src/model.py:153-155), a unit-scale normal around
+    softplus(MLP_g(x)) + 1e-6 (src/distribution/poisson.py:33-38), with no scale variable"""
+    from psvo_amd.distribution.poisson import tf_poisson
+    FLAGS = Hh.make_flags("AESMC", poisson_emission=True, Dx=3, Dy=2)
+    torch.manual_seed(5)
+    m = Hh.perturb_(SSM(FLAGS))
+    assert isinstance(m.g_dist, tf_poisson) and not hasattr(m.g_dist, "sigma_con")
+    assert not any("g_dist.sigma" in n for n, _ in m.named_parameters())
+    P = m.export_reference_layout(torch.float64)
+    assert "sigma_raw" not in P["g"]
+    og = O.OracleSVO(P, Hh.oracle_flags(FLAGS, "AESMC"), smooth_obs=False).g
+    x, y = torch.randn(7, 5, 3) * 3, torch.randn(7, 5, 2)
+    assert torch.allclose(m.g_dist.mean(x).double(), og.mean(x.double()), atol=1e-6)
+    assert float(m.g_dist.mean(x).min()) > 0
+    assert torch.allclose(m.g_dist.log_prob(x, y).double(), og.log_prob(x.double(), y.double()), atol=1e-5)
+    # closed form: -0.5 |y - lambda|^2 - Dy/2 log(2 pi)
+    lam = og.mean(x.double())
+    want = -0.5 * ((y.double() - lam) ** 2).sum(-1) - math.log(2 * math.pi)
+    assert torch.allclose(og.log_prob(x.double(), y.double()), want, atol=1e-12)
+    assert torch.equal(m.g_dist.get_sigma(), torch.ones(2))
+    m2 = SSM(FLAGS).load_reference_layout(P)
+    assert torch.equal(m2.g_tran.mu_kernel, m.g_tran.mu_kernel)
 
 
 def test_export_import_roundtrip_and_sigma():

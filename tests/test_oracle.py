@@ -130,10 +130,10 @@ def test_linear_gaussian_ssm_matches_kalman_likelihood():
     assert abs(float(z) - ll / B) < 0.05, (float(z), ll / B)
 
 
-@pytest.mark.parametrize("objective", ["PSVO", "PSVOwR"])
-def test_oracle_autograd_matches_finite_differences(objective):
-    """teacher-forced indices make log_ZSMC a smooth function of the parameters"""
-    fl = _flags(objective, n_particles=5, n_particles_for_BSim_proposal=3)
+@pytest.mark.parametrize("objective,poisson", [("PSVO", False), ("PSVOwR", False), ("PSVO", True)])
+def test_oracle_autograd_matches_finite_differences(objective, poisson):
+    """teacher-forced indices make log_ZSMC a smooth function of the parameters (also with the tf_poisson emission)"""
+    fl = _flags(objective, n_particles=5, n_particles_for_BSim_proposal=3, poisson_emission=poisson)
     Oracle = O.OBJECTIVES[objective]
     P = O.make_params(fl, seed=2, bias_scale=0.3)
     for k in P:
