@@ -5,9 +5,11 @@
 // The cross-chain draw couples all N chains of a sequence once per step.  A sequence is therefore owned by a
 // CLUSTER of K persistent workgroups (K = 1, 2, 4 or 8; cooperative launch, so that all of them are resident):
 // workgroup k walks the (chain, sub-particle) items of chains [k Nc, (k+1) Nc), publishes the selected
-// sub-particle, its normalised log-weight omega_sel and the step weight of each of its chains to HBM, meets
-// the others at a per-sequence barrier (one agent-scope atomic counter per sequence, bounded spin), and then
-// every workgroup rebuilds the N-entry CDF and draws the ancestors of ITS OWN chains -- one barrier per step.
+// sub-particle, its normalised log-weight omega_sel and the step weight of each of its chains as TAGGED 64-bit
+// words {value, step tag} in a two-step ring in HBM; every workgroup then polls the N chains' words until the
+// tags match (bounded spin), rebuilds the N-entry CDF and draws the ancestors of ITS OWN chains.  The data words
+// are the synchronisation: no counter barrier, no store acknowledgement to wait for and no second round trip for
+// the gathered states -- one one-way HBM hop per step instead of five serialised ones.
 // The per-item work is the arithmetic of psvo_bsim_forward (packed f32 pair loop over the LDS-staged tile).
 //
 // With omega_raw = Lambda + phi + g - q the reference's per-step weight
@@ -28,49 +30,25 @@ struct WrArgs {
     float *bwX, *bwXanc, *bwW, *lseW;
     int32_t *sel_out, *anc_out;
     float *lam2_all, *om_all, *mu1_all;
-    float* omS;        // (T,B,N) workspace: omega_sel of every chain (logits of the cross-chain draw)
-    unsigned* sync;    // B barrier counters + 1 error flag (zeroed before the launch)
+    unsigned long long* ring;   // [2][B][N][kWrWords] tagged words {bits(value), t + 1} (zeroed before the launch)
+    unsigned* err;              // error flag: a poll timed out (zeroed before the launch)
 };
+
+// words a chain publishes per step: Dx selected states, omega_sel, bw_log_W (sized for Dx <= 4)
+constexpr int kWrWords = 6;
+
+__device__ __forceinline__ void st_tagged(unsigned long long* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// workspace: the ring [2][B][N][kWrWords] of 64-bit words, then two 32-bit words whose last one is the error flag
+static inline long long wr_ws_floats(int B, int N) { return 2ll * (2ll * B * N * kWrWords) + 2; }
 
 template <int DX>
 struct WrSlot {
     static constexpr int kFloats = (DX <= 3) ? 4 : 8;
 };
-
-// loads of data another workgroup of the cluster wrote before the barrier: agent scope (the per-XCD L2s are
-// not coherent with each other for ordinary cached loads)
-__device__ __forceinline__ float ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Barrier over the K workgroups of a sequence.  `target` = K * (number of barriers passed so far + 1).
-// The spin is bounded: on a timeout (or once another workgroup flagged one) the error flag is raised and every
-// later barrier falls through, so the grid always drains.
-__device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned* err, unsigned target, int K) {
-    __builtin_amdgcn_s_waitcnt(0);      // this lane's agent-scope stores have been acknowledged
-    __syncthreads();
-    if (K > 1) {
-        if (threadIdx.x == 0) {
-            // Everything the other workgroups read was written with agent-scope stores (write-through to the
-            // coherence point) and has completed (__syncthreads waits for this workgroup's stores), and it is read
-            // back with agent-scope loads: no L2 write-back / invalidate (__threadfence) is needed -- on this
-            // 8-XCD part that fence costs several microseconds per step.
-            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
 
 template <int DX>
 __device__ __forceinline__ void wr_read_slot(const float* p, float (&F)[DX], float& W) {
@@ -106,8 +84,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
     const int rounds = (Nc + cpr - 1) / cpr;
     const int cl = tid / M, m = tid % M, q = m & 3;
     const int gbase = lane - m;
-    unsigned* const bar = a.sync + b;
-    unsigned* const err = a.sync + B;
+    unsigned* const err = a.err;
 
     float* wf = smem;
     float* wg = wf + MQ::kSize;
@@ -115,7 +92,8 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
     float* tile = wqi + MQ::kSize;                 // [2][NP][PS]
     float* xanc = tile + 2 * NP * PS;              // [DX][Nc] resampled states (x_{t+1}) of this workgroup's chains
     float* cdf = xanc + DX * Nc;                   // [N]      CDF of the cross-chain draw
-    float* red = cdf + N;                          // 64 floats scratch
+    float* xall = cdf + N;                         // [DX][N]  selected states of all chains (polled from the ring)
+    float* red = xall + DX * N;                    // 64 floats scratch
 
     MQ::load(wf, a.f, tid, NTB);
     MG::load(wg, a.g, tid, NTB);
@@ -187,9 +165,12 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
     if (T >= 2) stage(T - 2, tile);
     __syncthreads();
 
-    unsigned nbar = 0;
     for (int t = T - 1; t >= 0; --t) {
         const size_t tb = (size_t)t * B + b;
+        // ring slot of the step: a workgroup can run at most one step ahead of the slowest one of its cluster (it needs
+        // everybody's step-t words to get past step t), so two slots suffice; the tag tells the steps apart
+        unsigned long long* const slot = a.ring + ((size_t)(t & 1) * B + b) * N * kWrWords;
+        const unsigned tag = (unsigned)(t + 1);
         const float* cur = tile + ((T - 1 - t) & 1) * NP * PS;
         float* nxt = tile + ((T - t) & 1) * NP * PS;
         const bool last = (t == T - 1);
@@ -350,22 +331,50 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
             const float om_s = __shfl(omega, src);
             const float phi_s = __shfl(phi, src);
             const float bw = lse_m - phi_s - logM;   // == (Lambda + g)_sel - q_sel - omega_sel - log M
-            if (valid && m == 0) {                   // published to the cluster through HBM
+            if (valid && m == 0) {                   // published to the cluster through the ring
+                unsigned long long* const w = slot + (size_t)n * kWrWords;
 #pragma unroll
-                for (int d = 0; d < DX; ++d) st_agent(a.bwX + (tb * DX + d) * N + n, xs[d]);
-                st_agent(a.omS + tb * N + n, om_s);
-                st_agent(a.bwW + tb * N + n, bw);
+                for (int d = 0; d < DX; ++d) st_tagged(w + d, xs[d], tag);
+                st_tagged(w + DX, om_s, tag);
+                st_tagged(w + DX + 1, bw, tag);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.bwX[(tb * DX + d) * N + n] = xs[d];
+                a.bwW[tb * N + n] = bw;
                 a.sel_out[tb * N + n] = sel;
             }
         }
-        cluster_barrier(bar, err, (unsigned)K * (++nbar), K);
 
         // ---- resample the chains: a[k] ~ Categorical(softmax_n omega_sel[n]) (PSVOwR.py:103,145,185); every workgroup
         //      rebuilds the CDF over all N chains and draws the ancestors of its own ----------------------------------
         {
             const bool act = tid < N;
-            const float lo = act ? ld_agent(a.omS + tb * N + tid) : ninf;
-            const float lw = (act && kb == 0) ? ld_agent(a.bwW + tb * N + tid) : ninf;
+            float lo = ninf, lw = ninf;
+            if (act) {   // poll chain `tid`'s words of this step (bounded: a timeout raises the error flag and drains)
+                const unsigned long long* const w = slot + (size_t)tid * kWrWords;
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned long long v[DX + 2];
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < DX + 2; ++i) {
+                        v[i] = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (unsigned)(v[i] >> 32) == tag;
+                    }
+                    if (ok) {
+#pragma unroll
+                        for (int d = 0; d < DX; ++d) xall[d * N + tid] = __uint_as_float((unsigned)v[d]);
+                        lo = __uint_as_float((unsigned)v[DX]);
+                        if (kb == 0) lw = __uint_as_float((unsigned)v[DX + 1]);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 21) ||
+                        ((spins & 63u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
             float m1 = wave_max(lo), m2 = wave_max(lw);
             if (lane == 0) {
                 red[wave] = m1;
@@ -413,8 +422,8 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
                 a.anc_out[tb * N + k] = anc;
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
-                    const float v = ld_agent(a.bwX + (tb * DX + d) * N + anc);
-                    xanc[d * Nc + tid] = v;         // (xanc is only read in the item rounds, after the barrier)
+                    const float v = xall[d * N + anc];   // (written before the CDF's workgroup barriers)
+                    xanc[d * Nc + tid] = v;         // (xanc is only read in the item rounds, after the closing barrier)
                     a.bwXanc[(tb * DX + d) * N + k] = v;
                 }
             }
@@ -438,10 +447,13 @@ static int launch_wr_fwd(const WrArgs& a, hipStream_t stream) {
     if (a.N > NTB) return PSVO_ERR_UNSUPPORTED;
     const int JB = NTB > 256 ? 4 : 16;
     const int NP = ((a.N + 4 * JB - 1) / (4 * JB)) * (4 * JB);
-    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)DX * Nc + a.N + 64);
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)DX * Nc + a.N +
+                                        (size_t)DX * a.N + 64);
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
-    if (hipMemsetAsync(a.sync, 0, sizeof(unsigned) * (a.B + 1), stream) != hipSuccess) return launch_status();
+    // tags of an earlier launch must not be mistaken for this one's: clear the ring and the error flag
+    if (hipMemsetAsync(a.ring, 0, sizeof(float) * (size_t)wr_ws_floats(a.B, a.N), stream) != hipSuccess)
+        return launch_status();
     WrArgs args = a;
     void* kargs[] = {(void*)&args};
     const dim3 grid(K, a.B), block(NTB);
@@ -492,7 +504,10 @@ static int wr_dispatch_dy(const WrArgs& a, int Dy, int H, int M, hipStream_t s) 
 
 extern "C" int psvo_bsimwr_blocks(int B, int N, int M) { return psvo::wr_cluster(B, N, M); }
 
-extern "C" long long psvo_bsimwr_ws_floats(int B, int T, int N) { return (long long)T * B * N + B + 1; }
+extern "C" long long psvo_bsimwr_ws_floats(int B, int T, int N) {
+    (void)T;
+    return psvo::wr_ws_floats(B, N);
+}
 
 extern "C" int psvo_bsimwr_forward(const psvo_desc* desc, const float* Fm, const float* logW, const float* lse,
                                    const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv, const float* sig_f,
@@ -519,8 +534,9 @@ extern "C" int psvo_bsimwr_forward(const psvo_desc* desc, const float* Fm, const
     a.obs = obs; a.eps_b = eps_b; a.u_b = u_b; a.u_r = u_r; a.sel_in = sel_in; a.anc_in = anc_in;
     a.bwX = bwX; a.bwXanc = bwXanc; a.bwW = bwW; a.lseW = lseW; a.sel_out = sel_out; a.anc_out = anc_out;
     a.lam2_all = lam2_all; a.om_all = om_all; a.mu1_all = mu1_all;
-    a.omS = ws;
-    a.sync = reinterpret_cast<unsigned*>(ws + (size_t)desc->T * desc->B * desc->N);
+    if (reinterpret_cast<uintptr_t>(ws) & 7u) return PSVO_ERR_INVALID;      // 64-bit words
+    a.ring = reinterpret_cast<unsigned long long*>(ws);
+    a.err = reinterpret_cast<unsigned*>(ws + wr_ws_floats(desc->B, desc->N) - 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {
         case 2: return wr_dispatch_dy<2>(a, desc->Dy, desc->H, desc->M, s);
