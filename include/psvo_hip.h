@@ -201,8 +201,9 @@ int psvo_bsim_backward(const psvo_desc* desc,
  *            sel_out, anc_out (T,B,N) drawn sub-particle / cross-chain ancestor indices
  *            lam2_all (T,B,N,M), om_all (T,B,N,M), mu1_all (T,B,Dx,N): optional saves for
  *            psvo_bsimwr_backward.
- *  ws      : workspace, psvo_bsimwr_ws_floats(B, T, N) floats (the chains' selected normalised log-weights
- *            and the per-sequence barrier counters; its last word is nonzero afterwards iff a barrier timed out).
+ *  ws      : workspace, psvo_bsimwr_ws_floats(B, T, N) floats, 8-byte aligned (a two-step ring of tagged 64-bit
+ *            words through which the workgroups of a sequence exchange the chains' selected states and
+ *            log-weights; its last word is nonzero afterwards iff a poll timed out).
  * ------------------------------------------------------------------------------------------- */
 int psvo_bsimwr_blocks(int B, int N, int M);
 long long psvo_bsimwr_ws_floats(int B, int T, int N);
@@ -230,8 +231,8 @@ int psvo_bsimwr_forward(const psvo_desc* desc,
  *            per-chain rows (to be summed over N) dbmu2_rows (T,B,Dx,N), dminit_rows (B,Dx,N),
  *            dimean_rows (B,Dx,N); scale gradients as psvo_bsim_backward.
  *  sacc    : workspace, B * K * psvo_bsim_acc_size(Dx, Dy) floats.
- *  ws      : workspace, psvo_bsimwr_bwd_ws_floats(B, T, N, Dx) floats (d loss / d bwXanc exchanged between the
- *            workgroups of a sequence, barrier counters; last word nonzero iff a barrier timed out).
+ *  ws      : workspace, psvo_bsimwr_bwd_ws_floats(B, T, N, Dx) floats, 8-byte aligned (d loss / d bwXanc exchanged
+ *            between the workgroups of a sequence as tagged 64-bit words; last word nonzero iff a poll timed out).
  * ------------------------------------------------------------------------------------------- */
 long long psvo_bsimwr_bwd_ws_floats(int B, int T, int N, int Dx);
 int psvo_bsimwr_backward(const psvo_desc* desc,

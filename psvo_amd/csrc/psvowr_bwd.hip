@@ -32,37 +32,15 @@ struct WrBwdArgs {
     float *dFm_part, *dlogW_part, *dlse_part;   // (T,B,K,Dx,N), (T,B,K,N), (T,B,K): per-workgroup partials
     float *dbmu2_rows, *dminit_rows, *dimean_rows;   // (T,B,Dx,N), (B,Dx,N), (B,Dx,N): per-chain rows
     float* sacc;                                 // (B,K,NACC)
-    float* dxg;                                  // (T,B,Dx,N) workspace: d loss / d bwXanc_t of every chain
-    unsigned* sync;                              // B barrier counters + 1 error flag
+    unsigned long long* ring;                    // exchange ring: d loss / d bwXanc_t of every chain, tagged
+    unsigned* err;                               // error flag: a poll timed out
 };
 
-__device__ __forceinline__ float wb_ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// barrier over the K workgroups of a sequence (see psvowr_fwd.hip: bounded spin, error flag)
-__device__ __forceinline__ void wb_cluster_barrier(unsigned* cnt, unsigned* err, unsigned target, int K) {
-    __builtin_amdgcn_s_waitcnt(0);      // this lane's agent-scope stores have been acknowledged
-    __syncthreads();
-    if (K > 1) {
-        if (threadIdx.x == 0) {
-            // Everything the other workgroups read was written with agent-scope stores (write-through to the
-            // coherence point) and has completed (__syncthreads waits for this workgroup's stores), and it is read
-            // back with agent-scope loads: no L2 write-back / invalidate (__threadfence) is needed -- on this
-            // 8-XCD part that fence costs several microseconds per step.
-            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
+// words a chain publishes per step (d loss / d bwXanc, Dx <= 4) and the exchange workspace: a two-step ring
+// [2][B][N][kWbWords] of tagged 64-bit words {bits(value), tag}, then two 32-bit words whose last one is the error flag
+// (protocol and the two-slot argument: psvowr_fwd.hip)
+constexpr int kWbWords = 4;
+static inline long long wb_ws_floats(int B, int N) { return 2ll * (2ll * B * N * kWbWords) + 2; }
 
 template <int DX, int DY>
 struct WAcc {   // same slots as BAcc in bsim_bwd_impl.h (shares bsim_bwd_finalize's algebra)
@@ -126,8 +104,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
     const int cpr = NTB / M;
     const int rounds = (Nc + cpr - 1) / cpr;
     const int cl = tid / M, m = tid % M, q = m & 3;
-    unsigned* const bar = a.sync + b;
-    unsigned* const err = a.sync + B;
+    unsigned* const err = a.err;
 
     float* wf = smem;
     float* wg = wf + MQ::kSize;
@@ -204,7 +181,6 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
     const bool owner = CH >= 16 || ((lane >> b3) & 1) == 0;
     __syncthreads();
 
-    unsigned nbar = 0;
     for (int t = 0; t < T; ++t) {
         const size_t tb = (size_t)t * B + b;
         const bool last = (t == T - 1), first = (t == 0);
@@ -218,12 +194,35 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
         for (int i = tid; i < nw * NA * NP; i += NTB) jacc[i] = 0.f;
         __syncthreads();
         if (t >= 1) {
+            const unsigned long long* const slot = a.ring + ((size_t)(t & 1) * B + b) * N * kWbWords;
+            const unsigned tag = (unsigned)(t + 1);
             for (int k = tid; k < N; k += NTB) {
                 const int p = a.anc[tb * N + k];
-                if (p >= c0 && p < c1) {
+                if (p >= c0 && p < c1) {   // poll chain k's words (its owner wrote them during step t-1; bounded spin)
+                    const unsigned long long* const w = slot + (size_t)k * kWbWords;
+                    unsigned spins = 0;
+                    for (;;) {
+                        unsigned long long v[DX];
+                        bool ok = true;
 #pragma unroll
-                    for (int d = 0; d < DX; ++d)
-                        atomicAdd(&dxs[d * Nc + (p - c0)], wb_ld_agent(a.dxg + (tb * DX + d) * N + k));
+                        for (int d = 0; d < DX; ++d) {
+                            v[d] = __hip_atomic_load(w + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && (unsigned)(v[d] >> 32) == tag;
+                        }
+                        if (ok) {
+#pragma unroll
+                            for (int d = 0; d < DX; ++d)
+                                atomicAdd(&dxs[d * Nc + (p - c0)], __uint_as_float((unsigned)v[d]));
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 21) ||
+                            ((spins & 63u) == 0u &&
+                             __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
                 }
             }
         }
@@ -442,9 +441,11 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
             if (lead) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
-                    if (!last)     // d loss / d bwXanc_{t+1}[n], read by the whole cluster after the barrier
-                        __hip_atomic_store(a.dxg + ((tb + B) * DX + d) * N + n, dxp[d], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                    if (!last)     // d loss / d bwXanc_{t+1}[n], polled by the parents' owners at step t+1 (tag t+2)
+                        __hip_atomic_store(a.ring + (((size_t)((t + 1) & 1) * B + b) * N + n) * kWbWords + d,
+                                           ((unsigned long long)(unsigned)(t + 2) << 32) |
+                                               (unsigned long long)__float_as_uint(dxp[d]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     a.dbmu2_rows[(tb * DX + d) * N + n] = last ? 0.f : outv[d];
                     if (last) a.dminit_rows[((size_t)b * DX + d) * N + n] = outv[d];
                     if (first) a.dimean_rows[((size_t)b * DX + d) * N + n] = dim[d];
@@ -485,8 +486,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
             }
             if (tid == 0) a.dlse_part[tb * K + kb] = 0.f;
         }
-        if (!last) wb_cluster_barrier(bar, err, (unsigned)K * (++nbar), K);   // d bwXanc_{t+1} of every chain is published
-        else __syncthreads();
+        __syncthreads();   // (dxs / jacc are cleared at the top of the next step)
     }
 
     for (int i = 0; i < AC::kN; ++i) {
@@ -555,7 +555,9 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
                                         (size_t)DX * Nc + 64);
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
-    if (hipMemsetAsync(a.sync, 0, sizeof(unsigned) * (a.B + 1), stream) != hipSuccess) return launch_status();
+    // tags of an earlier launch must not be mistaken for this one's: clear the ring and the error flag
+    if (hipMemsetAsync(a.ring, 0, sizeof(float) * (size_t)wb_ws_floats(a.B, a.N), stream) != hipSuccess)
+        return launch_status();
     WrBwdArgs args = a;
     void* kargs[] = {(void*)&args};
     const hipError_t e = hipLaunchCooperativeKernel((const void*)psvowr_bwd_kernel<DX, DY, H, M>, dim3(K, a.B), dim3(NTB),
@@ -603,7 +605,8 @@ static int wb_dispatch_dy(const WrBwdArgs& a, const WrBwdOut& o, int Dy, int H, 
 }  // namespace psvo
 
 extern "C" long long psvo_bsimwr_bwd_ws_floats(int B, int T, int N, int Dx) {
-    return (long long)T * B * Dx * N + B + 1;
+    (void)T; (void)Dx;
+    return psvo::wb_ws_floats(B, N);
 }
 
 extern "C" int psvo_bsimwr_backward(
@@ -635,8 +638,9 @@ extern "C" int psvo_bsimwr_backward(
     a.xt = xt; a.dFt = dFt; a.dGt = dGt; a.dmu1 = dmu1;
     a.dFm_part = dFm_part; a.dlogW_part = dlogW_part; a.dlse_part = dlse_part;
     a.dbmu2_rows = dbmu2_rows; a.dminit_rows = dminit_rows; a.dimean_rows = dimean_rows; a.sacc = sacc;
-    a.dxg = ws;
-    a.sync = reinterpret_cast<unsigned*>(ws + (size_t)desc->T * desc->B * desc->Dx * desc->N);
+    if (reinterpret_cast<uintptr_t>(ws) & 7u) return PSVO_ERR_INVALID;      // 64-bit words
+    a.ring = reinterpret_cast<unsigned long long*>(ws);
+    a.err = reinterpret_cast<unsigned*>(ws + wb_ws_floats(desc->B, desc->N) - 1);
     WrBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {
