@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NTB = blockDim.x, nw = NTB >> 6;
     const int B = a.B, T = a.T, N = a.N;
-    const int NP = (N + 3) & ~3;
+    const int NP = ((N + 4 * CH - 1) / (4 * CH)) * (4 * CH);   // tile padded (W' = -inf) to whole chunks: no predication
     const int b = blockIdx.y, kb = blockIdx.x, K = gridDim.x;
     const int Nc = (N + K - 1) / K;                // chains per workgroup
     const int c0 = kb * Nc, c1 = min(N, c0 + Nc);  // this workgroup's chains
@@ -271,49 +271,51 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
 
             if (!first) {
                 const float lam2 = a.lam2_all[(tb * N + n) * M + m];
-                float xq[4][DX], lq[4], dl[4], U[4][DX], V[4][DX];
+                // packed f32: sub-particles (0,1) and (2,3) of the quad share every v_pk_* instruction (as bsim_bwd_impl.h)
+                float lq[4], dl[4];
                 quad_bcast4(lam2, lq);
                 quad_bcast4(cg, dl);
+                const f2 lqa = f2{lq[0], lq[1]}, lqb = f2{lq[2], lq[3]};
+                const f2 dla = f2{dl[0], dl[1]}, dlb = f2{dl[2], dl[3]};
+                f2 xa[DX], xb[DX], Ua[DX], Ub[DX], Va[DX], Vb[DX];
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
                     float t4[4];
                     quad_bcast4(x[d] * rp[d], t4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        xq[i][d] = t4[i];
-                        U[i][d] = 0.f;
-                        V[i][d] = 0.f;
-                    }
+                    xa[d] = f2{t4[0], t4[1]};
+                    xb[d] = f2{t4[2], t4[3]};
+                    Ua[d] = Ub[d] = Va[d] = Vb[d] = f2{0.f, 0.f};
                 }
-                for (int c0 = 0; c0 < nq; c0 += CH) {
+                for (int c0 = 0; c0 < nq; c0 += CH) {   // nq is a multiple of CH
                     float A[CH][NA];
 #pragma unroll
                     for (int i2 = 0; i2 < CH; ++i2) {
-                        const int e = c0 + i2;
+                        float F[DX], W;
+                        wb_read_slot<DX>(cur + ((c0 + i2) * 4 + q) * PS, F, W);
+                        f2 ua[DX], ub[DX], la = f2{W, W}, lb = la;
 #pragma unroll
-                        for (int d = 0; d < NA; ++d) A[i2][d] = 0.f;
-                        if (e < nq) {
-                            float F[DX], W;
-                            wb_read_slot<DX>(cur + (e * 4 + q) * PS, F, W);
+                        for (int d = 0; d < DX; ++d) {
+                            const f2 Fd = f2{F[d], F[d]};
+                            ua[d] = xa[d] - Fd;
+                            ub[d] = xb[d] - Fd;
+                            la = pk_fma(-ua[d], ua[d], la);
+                            lb = pk_fma(-ub[d], ub[d], lb);
+                        }
+                        la -= lqa;
+                        lb -= lqb;
+                        const f2 pa = f2{exp2_fast(la.x), exp2_fast(la.y)}, pb = f2{exp2_fast(lb.x), exp2_fast(lb.y)};
+                        const f2 ca = dla * pa, cb = dlb * pb;
+                        const f2 cs = ca + cb;
+                        A[i2][DX] = cs.x + cs.y;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                float u[DX], l = W;
-#pragma unroll
-                                for (int d = 0; d < DX; ++d) {
-                                    u[d] = xq[i][d] - F[d];
-                                    l = fmaf(-u[d], u[d], l);
-                                }
-                                const float p = exp2_fast(l - lq[i]);
-                                const float c = dl[i] * p;
-                                A[i2][DX] += c;
-#pragma unroll
-                                for (int d = 0; d < DX; ++d) {
-                                    const float pu = p * u[d];
-                                    U[i][d] += pu;
-                                    V[i][d] = fmaf(pu, u[d], V[i][d]);
-                                    A[i2][d] = fmaf(c, u[d], A[i2][d]);
-                                }
-                            }
+                        for (int d = 0; d < DX; ++d) {
+                            const f2 pua = pa * ua[d], pub = pb * ub[d];
+                            Ua[d] += pua;
+                            Ub[d] += pub;
+                            Va[d] = pk_fma(pua, ua[d], Va[d]);
+                            Vb[d] = pk_fma(pub, ub[d], Vb[d]);
+                            const f2 ad = pk_fma(cb, ub[d], ca * ua[d]);
+                            A[i2][d] = ad.x + ad.y;
                         }
                     }
                     wb_rs_stage<CH, NA, CH, (1 << b0)>(A, (lane >> b0) & 1);
@@ -326,7 +328,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                         for (int d = 0; d < NA; ++d) A[0][d] += xor_lane<(1 << b3)>(A[0][d]);
                     }
                     const int e = c0 + ebase;       // the one entry this lane owns; the wave's rounds accumulate
-                    if (owner && e < nq) {
+                    if (owner) {
 #pragma unroll
                         for (int d = 0; d < NA; ++d) ja[d * NP + e * 4 + q] += A[0][d];
                     }
@@ -341,7 +343,10 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int d = 0; d < DX; ++d) {
-                        const float u = group_sum<4>(U[i][d]), v = group_sum<4>(V[i][d]);
+                        float u = (i == 0) ? Ua[d].x : (i == 1) ? Ua[d].y : (i == 2) ? Ub[d].x : Ub[d].y;
+                        float v = (i == 0) ? Va[d].x : (i == 1) ? Va[d].y : (i == 2) ? Vb[d].x : Vb[d].y;
+                        u = group_sum<4>(u);
+                        v = group_sum<4>(v);
                         if (i == q) {
                             Uo[d] = u;
                             Vo[d] = v;
@@ -544,7 +549,8 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
     constexpr int PS = WbSlot<DX>::kFloats;
-    const int NP = (a.N + 3) & ~3;
+    constexpr int CH = (DX <= 2) ? 16 : 8;         // (as in the kernel)
+    const int NP = ((a.N + 4 * CH - 1) / (4 * CH)) * (4 * CH);
     const int K = wr_cluster(a.B, a.N, M);
     const int Nc = (a.N + K - 1) / K;
     long long items = (long long)Nc * M;
