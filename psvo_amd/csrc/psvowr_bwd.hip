@@ -67,6 +67,13 @@ __device__ __forceinline__ void wb_read_slot(const float* p, float (&F)[DX], flo
     }
 }
 
+template <int DX>
+struct WbIn {   // what an item reads from the forward pass's saves
+    float bww, om, lam2;
+    int sel;
+    float eps[DX], xp[DX], mu1[DX];
+};
+
 template <int CH, int NA, int NN, int MASK>
 __device__ __forceinline__ void wb_rs_stage(float (&A)[CH][NA], int bit) {
 #pragma unroll
@@ -171,6 +178,23 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
     };
     if (T >= 2) stage(0, tile);   // step t reads forward tile t-1
 
+    // per-item inputs of round r of step tb (issue only)
+    auto load_in = [&](size_t tb, int r, bool last, bool first, WbIn<DX>& s) {
+        const int n_raw = c0 + r * cpr + cl;
+        const bool valid = n_raw < c1 && (r * cpr + cl) < Nc;
+        const int n = valid ? n_raw : max(c1 - 1, 0);
+        s.bww = a.bwW[tb * N + n];
+        s.sel = a.sel[tb * N + n];
+        s.om = a.om_all[(tb * N + n) * M + m];
+        s.lam2 = first ? 0.f : a.lam2_all[(tb * N + n) * M + m];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            s.eps[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
+            s.xp[d] = last ? 0.f : a.bwXanc[((tb + B) * DX + d) * N + n];
+            s.mu1[d] = last ? 0.f : a.mu1_all[(tb * DX + d) * N + n];
+        }
+    };
+
     float acc[AC::kN];
 #pragma unroll
     for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
@@ -187,6 +211,17 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
         const float* cur = tile + ((t + 1) & 1) * NP * PS;   // tile(t-1)
         float* nxt = tile + (t & 1) * NP * PS;               // tile(t), read at step t+1
         if (t + 1 < T && t >= 1) stage(t, nxt);
+
+        // per-step inputs and the first round's per-item inputs (all saved by the forward pass) are requested BEFORE the
+        // exchange below, so that their HBM latency hides behind the poll; issue only -- no arithmetic on them here
+        float bm[DX], y[DY];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) bm[d] = a.bmu2[tb * DX + d];
+#pragma unroll
+        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+        const float lw = a.lseW[tb], dlw = a.dlseW[tb];
+        WbIn<DX> in0;
+        load_in(tb, 0, last, first, in0);
 
         // ---- phase 0: scatter d bwXanc_t of ALL chains to the parents this workgroup owns
         //      (bwXanc_t[k] = bwX_t[anc_t[k]]; d bwXanc_t was published by the owners during step t-1) -----------------
@@ -228,12 +263,6 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
         }
         __syncthreads();
 
-        float bm[DX], y[DY];
-#pragma unroll
-        for (int d = 0; d < DX; ++d) bm[d] = a.bmu2[tb * DX + d];
-#pragma unroll
-        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
-        const float lw = a.lseW[tb], dlw = a.dlseW[tb];
         float* ja = jacc + wave * NA * NP;
 
         // ---- phase 1: the (chain, sub-particle) items ----------------------------------------------------------
@@ -242,15 +271,18 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
             const bool valid = n_raw < c1 && (r * cpr + cl) < Nc;
             const int n = valid ? n_raw : max(c1 - 1, 0);
             const int nl = n - c0;
-            const float aw = valid ? dlw * expf(a.bwW[tb * N + n] - lw) : 0.f;   // d loss / d bw_log_W[t, n]
-            const int sel = a.sel[tb * N + n];
+            WbIn<DX> in;
+            if (r == 0) in = in0;
+            else load_in(tb, r, last, first, in);
+            const float aw = valid ? dlw * expf(in.bww - lw) : 0.f;   // d loss / d bw_log_W[t, n]
+            const int sel = in.sel;
             float xp[DX], eps[DX], mu1[DX], mu[DX], x[DX];
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
-                eps[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
+                eps[d] = in.eps[d];
                 if (!last) {
-                    xp[d] = a.bwXanc[((tb + B) * DX + d) * N + n];
-                    mu1[d] = a.mu1_all[(tb * DX + d) * N + n];
+                    xp[d] = in.xp[d];
+                    mu1[d] = in.mu1[d];
                     mu[d] = pc[d] * fmaf(pi1[d], mu1[d], pi2[d] * bm[d]);
                     x[d] = fmaf(pc[d], eps[d], mu[d]);
                 } else {
@@ -260,7 +292,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                     x[d] = fmaf(s_init[d], eps[d], mu[d]);
                 }
             }
-            const float pi_m = valid ? expf(a.om_all[(tb * N + n) * M + m]) : 0.f;
+            const float pi_m = valid ? expf(in.om) : 0.f;
             const float issel = (m == sel) ? 1.f : 0.f;
             const float cg = aw * pi_m;                 // d g_m = d Lambda_m = d iota_m
             const float cphi = aw * (pi_m - issel);     // d phi_m
@@ -270,7 +302,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
             for (int d = 0; d < DX; ++d) dxt[d] = issel * dxs[d * Nc + nl];
 
             if (!first) {
-                const float lam2 = a.lam2_all[(tb * N + n) * M + m];
+                const float lam2 = in.lam2;
                 // packed f32: sub-particles (0,1) and (2,3) of the quad share every v_pk_* instruction (as bsim_bwd_impl.h)
                 float lq[4], dl[4];
                 quad_bcast4(lam2, lq);

@@ -165,6 +165,21 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
     if (T >= 2) stage(T - 2, tile);
     __syncthreads();
 
+    // per-step inputs and round 0's noise, loaded one exchange ahead
+    float bm_n[DX], y_n[DY], eps_n[DX];
+    auto load_step = [&](size_t tb) {
+        const bool valid0 = (c0 + cl) < c1 && cl < Nc;
+        const int n0 = valid0 ? c0 + cl : max(c1 - 1, 0);
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            bm_n[d] = a.bmu2[tb * DX + d];
+            eps_n[d] = a.eps_b[((tb * DX + d) * N + n0) * M + m];
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) y_n[k] = a.obs[tb * DY + k];
+    };
+    load_step((size_t)(T - 1) * B + b);
+
     for (int t = T - 1; t >= 0; --t) {
         const size_t tb = (size_t)t * B + b;
         // ring slot of the step: a workgroup can run at most one step ahead of the slowest one of its cluster (it needs
@@ -178,9 +193,9 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
 
         float bm[DX], y[DY];
 #pragma unroll
-        for (int d = 0; d < DX; ++d) bm[d] = a.bmu2[tb * DX + d];
+        for (int d = 0; d < DX; ++d) bm[d] = bm_n[d];
 #pragma unroll
-        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+        for (int k = 0; k < DY; ++k) y[k] = y_n[k];
 
         for (int r = 0; r < rounds; ++r) {
             const int n_raw = c0 + r * cpr + cl;
@@ -191,7 +206,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
                 xp[d] = last ? 0.f : xanc[d * Nc + nl];
-                eps[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
+                eps[d] = (r == 0) ? eps_n[d] : a.eps_b[((tb * DX + d) * N + n) * M + m];
             }
             // ---- proposal ------------------------------------------------------------------------
             float x[DX], q_lp;
@@ -347,6 +362,8 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
         // ---- resample the chains: a[k] ~ Categorical(softmax_n omega_sel[n]) (PSVOwR.py:103,145,185); every workgroup
         //      rebuilds the CDF over all N chains and draws the ancestors of its own ----------------------------------
         {
+            // the next step's inputs are requested before the poll so that their HBM latency hides behind it (issue only)
+            if (t > 0) load_step(tb - B);
             const bool act = tid < N;
             float lo = ninf, lw = ninf;
             if (act) {   // poll chain `tid`'s words of this step (bounded: a timeout raises the error flag and drains)
