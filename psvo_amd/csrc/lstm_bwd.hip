@@ -58,23 +58,55 @@ __global__ void __launch_bounds__(4 * DH) bilstm_bwd_kernel(const LstmBwdArgs a)
     float* dxb = a.dx_part + ((size_t)dir * B + b) * T * Din;
     __syncthreads();
 
-    // reverse of the direction's forward order
-    for (int s = 0; s < T; ++s) {
+    // Everything a step reads from HBM was saved by the forward pass, so it is requested one step ahead (issue only:
+    // no arithmetic on the loaded values here) -- otherwise every one of the T dependent steps starts with an exposed
+    // HBM round trip, which was most of this kernel's time.
+    struct StepIn {
+        float xv[RPT];                       // rows of [x_t, h_{t-1}] this thread stages
+        float gi, gj, gf, go, c, cprev, dout;
+    };
+    auto load_step = [&](int s, StepIn& in) {
         const int t = dir ? s : T - 1 - s;
         const int tprev = t - dtf;
         const bool has_prev = dir ? (t < T - 1) : (t > 0);
-        for (int p = g; p < K; p += NTH) {
-            float v;
-            if (p < DINP) v = p < Din ? xb[(size_t)t * Din + p] : 0.f;
-            else v = has_prev ? ob[(size_t)tprev * 2 * DH + (p - DINP)] : 0.f;
-            xh[p] = v;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int p = g + r * NTH;
+            float v = 0.f;
+            if (p < DINP) {
+                if (p < Din) v = xb[(size_t)t * Din + p];
+            } else if (p < K && has_prev) {
+                v = ob[(size_t)tprev * 2 * DH + (p - DINP)];
+            }
+            in.xv[r] = v;
         }
         if (g < DH) {
-            const float gi = gb[(size_t)t * NTH + g], gj = gb[(size_t)t * NTH + DH + g];
-            const float gf = gb[(size_t)t * NTH + 2 * DH + g], go = gb[(size_t)t * NTH + 3 * DH + g];
-            const float c = csb[(size_t)t * DH + g];
-            const float cprev = has_prev ? csb[(size_t)tprev * DH + g] : 0.f;
-            const float dh = dob[(size_t)t * 2 * DH + g] + dhrec[g];
+            in.gi = gb[(size_t)t * NTH + g];
+            in.gj = gb[(size_t)t * NTH + DH + g];
+            in.gf = gb[(size_t)t * NTH + 2 * DH + g];
+            in.go = gb[(size_t)t * NTH + 3 * DH + g];
+            in.c = csb[(size_t)t * DH + g];
+            in.cprev = has_prev ? csb[(size_t)tprev * DH + g] : 0.f;
+            in.dout = dob[(size_t)t * 2 * DH + g];
+        }
+    };
+    StepIn cur;
+    load_step(0, cur);
+
+    // reverse of the direction's forward order
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : T - 1 - s;
+        StepIn nxt = cur;
+        if (s + 1 < T) load_step(s + 1, nxt);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int p = g + r * NTH;
+            if (p < K) xh[p] = cur.xv[r];
+        }
+        if (g < DH) {
+            const float gi = cur.gi, gj = cur.gj, gf = cur.gf, go = cur.go;
+            const float c = cur.c, cprev = cur.cprev;
+            const float dh = cur.dout + dhrec[g];
             const float tc = tanhf(c);
             const float dc = dcrec + dh * go * (1.f - tc * tc);
             dz[g] = dc * gj * gi * (1.f - gi);
@@ -117,6 +149,7 @@ __global__ void __launch_bounds__(4 * DH) bilstm_bwd_kernel(const LstmBwdArgs a)
             }
         }
         __syncthreads();
+        cur = nxt;
     }
     // partial weight gradients of this (sequence, direction)
     float* dWp = a.dW_part + ((size_t)b * 2 + dir) * (size_t)(Din + DH) * NTH;
