@@ -72,5 +72,13 @@ class PSVOwR(PSVO):
             *model.f_tran.hip_params(), *model.g_tran.hip_params(), *model.q1_inv_tran.hip_params(),
             self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
             bmu2, minit, self._sigma(self.BSim_q_init), imean, isig)
-        # ws[-1] (as int32) is nonzero iff a cluster barrier of the kernel timed out (checked by the tests)
+        # ws[-1] (as int32) is nonzero iff an exchange poll of the kernel timed out (check_exchange, the tests)
+        self._last_ws = ws
         return {"lseW": lseW, "bwXanc": bwXanc, "bwX": bwX, "bwW": bwW, "sel": sel, "anc": anc, "ws": ws}
+
+    def check_exchange(self):
+        """Raise if the workgroups of a sequence lost each other in the most recent evaluation (a bounded poll of
+        psvo_bsimwr_forward timed out and the kernel drained with garbage).  Synchronises: called between epochs."""
+        ws = getattr(self, "_last_ws", None)
+        if ws is not None and int(ws[-1:].view(torch.int32)) != 0:
+            raise RuntimeError("psvo_bsimwr_forward: an exchange poll between the workgroups of a sequence timed out")

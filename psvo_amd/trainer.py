@@ -181,6 +181,9 @@ class trainer:
                 self.train_step(obs_train[j:j + self.batch_size], hidden_train[j:j + self.batch_size], self.lr)
 
             if (i + 1) % print_freq == 0:
+                check = getattr(self.SMC, "check_exchange", None)      # (PSVOwR: the kernels' bounded polls)
+                if check is not None:
+                    check()
                 try:
                     self.evaluate_and_save_metrics(i)
                     self.adjust_lr(i, print_freq)
