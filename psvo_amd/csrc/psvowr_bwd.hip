@@ -223,44 +223,8 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
         WbIn<DX> in0;
         load_in(tb, 0, last, first, in0);
 
-        // ---- phase 0: scatter d bwXanc_t of ALL chains to the parents this workgroup owns
-        //      (bwXanc_t[k] = bwX_t[anc_t[k]]; d bwXanc_t was published by the owners during step t-1) -----------------
         for (int i = tid; i < DX * Nc; i += NTB) dxs[i] = 0.f;
         for (int i = tid; i < nw * NA * NP; i += NTB) jacc[i] = 0.f;
-        __syncthreads();
-        if (t >= 1) {
-            const unsigned long long* const slot = a.ring + ((size_t)(t & 1) * B + b) * N * kWbWords;
-            const unsigned tag = (unsigned)(t + 1);
-            for (int k = tid; k < N; k += NTB) {
-                const int p = a.anc[tb * N + k];
-                if (p >= c0 && p < c1) {   // poll chain k's words (its owner wrote them during step t-1; bounded spin)
-                    const unsigned long long* const w = slot + (size_t)k * kWbWords;
-                    unsigned spins = 0;
-                    for (;;) {
-                        unsigned long long v[DX];
-                        bool ok = true;
-#pragma unroll
-                        for (int d = 0; d < DX; ++d) {
-                            v[d] = __hip_atomic_load(w + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = ok && (unsigned)(v[d] >> 32) == tag;
-                        }
-                        if (ok) {
-#pragma unroll
-                            for (int d = 0; d < DX; ++d)
-                                atomicAdd(&dxs[d * Nc + (p - c0)], __uint_as_float((unsigned)v[d]));
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 21) ||
-                            ((spins & 63u) == 0u &&
-                             __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                }
-            }
-        }
         __syncthreads();
 
         float* ja = jacc + wave * NA * NP;
@@ -299,7 +263,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
 
             float dxt[DX];
 #pragma unroll
-            for (int d = 0; d < DX; ++d) dxt[d] = issel * dxs[d * Nc + nl];
+            for (int d = 0; d < DX; ++d) dxt[d] = 0.f;
 
             if (!first) {
                 const float lam2 = in.lam2;
@@ -438,6 +402,49 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                 }
                 MG::template bwd_input<kRolled>(wg, x, dGo, dxt);
             }
+
+            // ---- exchange: scatter d bwXanc_t of ALL chains to the parents this workgroup owns (bwXanc_t[k] =
+            //      bwX_t[anc_t[k]]; the owners published d bwXanc_t at the end of their step t-1).  Nothing above depends
+            //      on it -- the pair loop and the f / g chains only add into dxt -- so the poll comes here, after them,
+            //      and its latency is hidden instead of opening every step. ----------------------------------------------
+            if (r == 0) {
+                if (t >= 1) {
+                    const unsigned long long* const slot = a.ring + ((size_t)(t & 1) * B + b) * N * kWbWords;
+                    const unsigned tag = (unsigned)(t + 1);
+                    for (int k = tid; k < N; k += NTB) {
+                        const int p = a.anc[tb * N + k];
+                        if (p >= c0 && p < c1) {   // poll chain k's words (its owner wrote them during step t-1; bounded spin)
+                            const unsigned long long* const w = slot + (size_t)k * kWbWords;
+                            unsigned spins = 0;
+                            for (;;) {
+                                unsigned long long v[DX];
+                                bool ok = true;
+#pragma unroll
+                                for (int d = 0; d < DX; ++d) {
+                                    v[d] = __hip_atomic_load(w + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    ok = ok && (unsigned)(v[d] >> 32) == tag;
+                                }
+                                if (ok) {
+#pragma unroll
+                                    for (int d = 0; d < DX; ++d)
+                                        atomicAdd(&dxs[d * Nc + (p - c0)], __uint_as_float((unsigned)v[d]));
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > (1u << 21) ||
+                                    ((spins & 63u) == 0u &&
+                                     __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    break;
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d) dxt[d] += issel * dxs[d * Nc + nl];
 
             // ---- reduce over the chain's M sub-particles --------------------------------------------------------
             float dmu[DX], sce[DX], dxp[DX], dim[DX];
