@@ -17,6 +17,8 @@
 
 namespace psvo {
 
+PSVO_TIMERS_DEFINE(psvowr_bwd)
+
 struct WrBwdArgs {
     int B, T, N, emission;
     psvo_mlp f, g, q1inv;
@@ -176,6 +178,42 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
             }
         }
     };
+    // One tile entry per thread (the usual case, NP <= workgroup size): the entry's raw values are only REQUESTED at the top
+    // of a step and scaled / stored at its end, so that no step opens with an exposed HBM round trip (stage() above
+    // does both at once and remains for larger N).
+    const bool one_entry = NP <= NTB;
+    float raw[DX + 1], rawl = 0.f;
+#pragma unroll
+    for (int d = 0; d <= DX; ++d) raw[d] = 0.f;
+    auto stage_load = [&](int tt) {
+        const size_t tb = (size_t)tt * B + b;
+        if (tid < NP) {
+            const int jc = tid < N ? tid : N - 1;
+#pragma unroll
+            for (int d = 0; d < DX; ++d) raw[d] = a.Fm[(tb * DX + d) * N + jc];
+            raw[DX] = a.logW[tb * N + jc];
+            rawl = a.lse[tb];
+        }
+    };
+    auto stage_store = [&](float* buf) {
+        if (tid < NP) {
+            float v[DX + 1];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) v[d] = raw[d] * rp[d];
+            v[DX] = tid < N ? (raw[DX] - rawl) * kLog2e : ninf;
+            if constexpr (DX <= 3) {
+                float4 o;
+                o.x = v[0];
+                o.y = DX > 1 ? v[DX > 1 ? 1 : 0] : 0.f;
+                o.z = DX > 2 ? v[DX > 2 ? 2 : 0] : 0.f;
+                o.w = v[DX];
+                *reinterpret_cast<float4*>(buf + tid * PS) = o;
+            } else {
+                *reinterpret_cast<float4*>(buf + tid * PS) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(buf + tid * PS + 4) = make_float4(v[4], 0.f, 0.f, 0.f);
+            }
+        }
+    };
     if (T >= 2) stage(0, tile);   // step t reads forward tile t-1
 
     // per-item inputs of round r of step tb (issue only)
@@ -205,12 +243,17 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
     const bool owner = CH >= 16 || ((lane >> b3) & 1) == 0;
     __syncthreads();
 
+    SEC_INIT(psvowr_bwd)
     for (int t = 0; t < T; ++t) {
         const size_t tb = (size_t)t * B + b;
         const bool last = (t == T - 1), first = (t == 0);
         const float* cur = tile + ((t + 1) & 1) * NP * PS;   // tile(t-1)
         float* nxt = tile + (t & 1) * NP * PS;               // tile(t), read at step t+1
-        if (t + 1 < T && t >= 1) stage(t, nxt);
+        const bool staging = (t + 1 < T && t >= 1);
+        if (staging) {
+            if (one_entry) stage_load(t);
+            else stage(t, nxt);
+        }
 
         // per-step inputs and the first round's per-item inputs (all saved by the forward pass) are requested BEFORE the
         // exchange below, so that their HBM latency hides behind the poll; issue only -- no arithmetic on them here
@@ -228,6 +271,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
         __syncthreads();
 
         float* ja = jacc + wave * NA * NP;
+        SEC(0);   // step inputs requested, accumulators cleared, barrier
 
         // ---- phase 1: the (chain, sub-particle) items ----------------------------------------------------------
         for (int r = 0; r < rounds; ++r) {
@@ -282,6 +326,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                     xb[d] = f2{t4[2], t4[3]};
                     Ua[d] = Ub[d] = Va[d] = Vb[d] = f2{0.f, 0.f};
                 }
+                SEC(1);   // item inputs, proposal recompute, coefficients
                 for (int c0 = 0; c0 < nq; c0 += CH) {   // nq is a multiple of CH
                     float A[CH][NA];
 #pragma unroll
@@ -329,6 +374,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                         for (int d = 0; d < NA; ++d) ja[d * NP + e * 4 + q] += A[0][d];
                     }
                 }
+                SEC(2);   // pair loop + butterflies
                 float Uo[DX], Vo[DX];
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
@@ -363,6 +409,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                 }
             }
 
+            SEC(3);   // quad merges
             float dxp_part[DX], dFo[DX];
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
@@ -407,6 +454,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
             //      bwX_t[anc_t[k]]; the owners published d bwXanc_t at the end of their step t-1).  Nothing above depends
             //      on it -- the pair loop and the f / g chains only add into dxt -- so the poll comes here, after them,
             //      and its latency is hidden instead of opening every step. ----------------------------------------------
+            SEC(4);   // MLP_f / MLP_g forward + input gradients, row stores
             if (r == 0) {
                 if (t >= 1) {
                     const unsigned long long* const slot = a.ring + ((size_t)(t & 1) * B + b) * N * kWbWords;
@@ -443,6 +491,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
                 }
                 __syncthreads();
             }
+            SEC(5);   // exchange poll + barrier
 #pragma unroll
             for (int d = 0; d < DX; ++d) dxt[d] += issel * dxs[d * Nc + nl];
 
@@ -498,6 +547,7 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
         }
         __syncthreads();
 
+        SEC(6);   // chain reductions, MLP_q1inv input gradient, publication, barrier
         // ---- phase 2: this workgroup's partial of d Fm[t-1] / d logW[t-1] / d lse[t-1] -----------------------------------
         if (!first) {
             const size_t tbm = tb - B;
@@ -530,7 +580,9 @@ __global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
             }
             if (tid == 0) a.dlse_part[tb * K + kb] = 0.f;
         }
+        if (staging && one_entry) stage_store(nxt);
         __syncthreads();   // (dxs / jacc are cleared at the top of the next step)
+        SEC(7);   // per-workgroup partials of d Fm / d logW / d lse, barrier
     }
 
     for (int i = 0; i < AC::kN; ++i) {

@@ -162,6 +162,42 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
             }
         }
     };
+    // One tile entry per thread (the usual case, NP <= workgroup size): the entry's raw values are only REQUESTED at the top
+    // of a step and scaled / stored at its end, so that no step opens with an exposed HBM round trip (stage() above
+    // does both at once and remains for larger N).
+    const bool one_entry = NP <= NTB;
+    float raw[DX + 1], rawl = 0.f;
+#pragma unroll
+    for (int d = 0; d <= DX; ++d) raw[d] = 0.f;
+    auto stage_load = [&](int tt) {
+        const size_t tb = (size_t)tt * B + b;
+        if (tid < NP) {
+            const int jc = tid < N ? tid : N - 1;
+#pragma unroll
+            for (int d = 0; d < DX; ++d) raw[d] = a.Fm[(tb * DX + d) * N + jc];
+            raw[DX] = a.logW[tb * N + jc];
+            rawl = a.lse[tb];
+        }
+    };
+    auto stage_store = [&](float* buf) {
+        if (tid < NP) {
+            float v[DX + 1];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) v[d] = raw[d] * rp[d];
+            v[DX] = tid < N ? (raw[DX] - rawl) * kLog2e : ninf;
+            if constexpr (DX <= 3) {
+                float4 o;
+                o.x = v[0];
+                o.y = DX > 1 ? v[DX > 1 ? 1 : 0] : 0.f;
+                o.z = DX > 2 ? v[DX > 2 ? 2 : 0] : 0.f;
+                o.w = v[DX];
+                *reinterpret_cast<float4*>(buf + tid * PS) = o;
+            } else {
+                *reinterpret_cast<float4*>(buf + tid * PS) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(buf + tid * PS + 4) = make_float4(v[4], 0.f, 0.f, 0.f);
+            }
+        }
+    };
     if (T >= 2) stage(T - 2, tile);
     __syncthreads();
 
@@ -189,7 +225,11 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
         const float* cur = tile + ((T - 1 - t) & 1) * NP * PS;
         float* nxt = tile + ((T - t) & 1) * NP * PS;
         const bool last = (t == T - 1);
-        if (t >= 2) stage(t - 2, nxt);   // consumed two barriers from now
+        const bool staging = (t >= 2);     // tile of step t-2, read during step t-1
+        if (staging) {
+            if (one_entry) stage_load(t - 2);
+            else stage(t - 2, nxt);
+        }
 
         float bm[DX], y[DY];
 #pragma unroll
@@ -445,6 +485,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
                 }
             }
         }
+        if (staging && one_entry) stage_store(nxt);
         __syncthreads();
     }
 }
