@@ -90,13 +90,14 @@ __device__ __forceinline__ void wb_rs_stage(float (&A)[CH][NA], int bit) {
     }
 }
 
-template <int DX, int DY, int H, int M>
-__global__ void __launch_bounds__(512) psvowr_bwd_kernel(const WrBwdArgs a) {
+// MAXT = 256: one wave per SIMD, so up to 512 VGPRs -- no scratch for Dx >= 3 and room to unroll the small MLPs.
+template <int DX, int DY, int H, int M, int MAXT>
+__global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
     using AC = WAcc<DX, DY>;
     constexpr int PS = WbSlot<DX>::kFloats;
-    constexpr bool kRolled = true;
+    constexpr bool kRolled = (MAXT > 256) || (H > 32) || (DX > 2);   // small MLPs: unrolled, their LDS reads overlap
     constexpr int NA = DX + 1;
     // forward-tile entries per butterfly: 16 (one owned entry per lane after four reduce-scatter stages over the 16
     // quads of a wave), or 8 for Dx >= 3 (three stages, then the two half-waves are summed) to stay inside 256 VGPRs
@@ -657,8 +658,9 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
         return launch_status();
     WrBwdArgs args = a;
     void* kargs[] = {(void*)&args};
-    const hipError_t e = hipLaunchCooperativeKernel((const void*)psvowr_bwd_kernel<DX, DY, H, M>, dim3(K, a.B), dim3(NTB),
-                                                    kargs, lds, stream);
+    const void* fn = NTB <= 256 ? (const void*)psvowr_bwd_kernel<DX, DY, H, M, 256>
+                                : (const void*)psvowr_bwd_kernel<DX, DY, H, M, 512>;
+    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(K, a.B), dim3(NTB), kargs, lds, stream);
     if (e != hipSuccess) {
         g_last_hip_error = e;
         (void)hipGetLastError();
