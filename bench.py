@@ -257,9 +257,6 @@ def main():
         opt.step(lr, world_size=world)
 
     use_graph, graph_note = args.graph, None
-    if use_graph and obj == "PSVOwR":
-        # cooperative launches (the cluster barrier needs all workgroups resident) are not captured: issue eagerly
-        use_graph, graph_note = False, "cooperative kernels are not graph-captured"
     eager_step = train_step if args.mode == "train" else fwd_step
     step = eager_step
     if use_graph:

@@ -127,9 +127,9 @@ class trainer:
     def _graphed_local_step(self, obs, hidden):
         """replay (capturing on first use) the hipGraph of the local step for this batch shape; None = run eagerly"""
         import os
-        if (not obs.is_cuda or os.environ.get("PSVO_HIPGRAPH", "1") == "0" or type(self.SMC).__name__ == "PSVOwR"
+        if (not obs.is_cuda or os.environ.get("PSVO_HIPGRAPH", "1") == "0"
                 or getattr(self.SMC, "generator", None) is None):
-            return None      # (PSVOwR: cooperative launches are not captured; a CPU generator cannot be registered)
+            return None      # (a CPU generator cannot be registered with the graph)
         graphs = self.__dict__.setdefault("_graphs", {})
         key = (tuple(obs.shape), tuple(hidden.shape))
         g = graphs.get(key)

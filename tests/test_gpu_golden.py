@@ -118,18 +118,18 @@ def test_adam_matches_tf_formula(built_lib):
     assert lin.weight.data_ptr() == flat.flat.data_ptr()
 
 
-@pytest.mark.parametrize("hipgraph", ["1", "0"])
-def test_trainer_improves_elbo(built_lib, tmp_path, monkeypatch, hipgraph):
+@pytest.mark.parametrize("objective,hipgraph", [("PSVO", "1"), ("PSVO", "0"), ("PSVOwR", "1")])
+def test_trainer_improves_elbo(built_lib, tmp_path, monkeypatch, objective, hipgraph):
     """a few epochs of the mirrored trainer on a small FHN set: ELBO goes up, artefacts are written
-    (local step replayed from a hipGraph, and issued eagerly)"""
+    (local step replayed from a hipGraph -- PSVOwR's cooperative kernels included -- and issued eagerly)"""
     monkeypatch.setenv("PSVO_HIPGRAPH", hipgraph)
     from oracle import psvo_oracle as O
     from psvo_amd.model import SSM
-    from psvo_amd.SMC.PSVO import PSVO
     from psvo_amd.trainer import trainer
+    PSVO = _objective(objective)
     monkeypatch.chdir(tmp_path)
     hid, obs = O.fhn_synthetic(12, 30, seed=0)
-    FLAGS = Hh.make_flags("PSVO", n_particles=16, n_particles_for_BSim_proposal=4, batch_size=4, time=30, epoch=4,
+    FLAGS = Hh.make_flags(objective, n_particles=16, n_particles_for_BSim_proposal=4, batch_size=4, time=30, epoch=4,
                           lr=1e-2, MSE_steps=5, saving_num=4, rslt_dir_name="t")
     torch.manual_seed(0); np.random.seed(0)
     model = SSM(FLAGS).cuda()

@@ -367,3 +367,36 @@ def test_short_sequences(built_lib, obj, T, N):
     zz = hip_pass()
     assert abs(float(zz.detach()) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
     _check_grads(model, P, rerun=hip_pass)
+
+
+def test_psvowr_step_replays_from_hipgraph(built_lib):
+    """The PSVOwR kernels are cooperative launches (a cluster of workgroups per sequence exchanges data through HBM).
+    Captured into a hipGraph and replayed, the local step must give the eagerly issued one's value bit for bit and its
+    gradients to rounding (the reverse kernel's cross-chain scatter is an LDS float atomic, so their summation order is not
+    fixed; fixed injected noise), replay after replay, and no exchange poll may time out."""
+    from psvo_amd.graph import GraphedStep
+    from psvo_amd.optim import FlatParams
+    FLAGS, model, smc, obs, noise = _setup("PSVOwR", 4, 12, 64, 8, 2, 1, 32, True, True, seed=3)
+    nz = Hh.noise_to_hip(noise, "cuda")
+    flat = FlatParams(model)
+    obs_c = obs.float().cuda()
+
+    def local():
+        flat.zero_grad()
+        z, _ = smc.get_log_ZSMC(obs_c, None, noise=nz)
+        z.backward()
+        return z.detach()
+    z_e = local().clone()
+    g_e = flat.grad.clone()
+    torch.cuda.synchronize()
+    smc.check_exchange()
+    assert torch.isfinite(z_e) and float(g_e.abs().max()) > 0
+    step = GraphedStep(local)
+    for _ in range(3):
+        flat.grad.fill_(float("nan"))          # the replay must rewrite every gradient itself
+        z_g = step()
+        torch.cuda.synchronize()
+        assert torch.equal(z_g, z_e)
+        assert torch.isfinite(flat.grad).all()
+        assert (flat.grad - g_e).abs().max() <= 1e-5 * float(g_e.abs().max())
+    smc.check_exchange()
