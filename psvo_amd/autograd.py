@@ -175,11 +175,14 @@ class BsimFunction(torch.autograd.Function):
         ctx.desc, ctx.filt, ctx.bs = desc, filt, bs
         ctx.saved = (f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b)
         ctx.mark_non_differentiable(bs["bwX"], bs["flp"], bs["glp"], bs["Omega"], bs["sel"])
+        ctx.set_materialize_grads(False)      # (else the engine zero-fills a gradient for each of the five constants)
         return bs["score"], bs["bwX"], bs["flp"], bs["glp"], bs["Omega"], bs["sel"]
 
     @staticmethod
     def backward(ctx, dscore, *_):
         desc = ctx.desc
+        if dscore is None:                    # (score unused by the loss)
+            dscore = torch.zeros(desc.B, desc.N, device=ctx.filt["Fm"].device)
         f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b = ctx.saved
         ov = getattr(desc, "_ov", None)
 
@@ -231,11 +234,14 @@ class BsimWRFunction(torch.autograd.Function):
         ctx.desc, ctx.filt, ctx.bs = desc, filt, bs
         ctx.saved = (f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b)
         ctx.mark_non_differentiable(bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"], bs["ws"])
+        ctx.set_materialize_grads(False)      # (else the engine zero-fills a gradient for each of the six constants)
         return bs["lseW"], bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"], bs["ws"]
 
     @staticmethod
     def backward(ctx, dlseW, *_):
         desc = ctx.desc
+        if dlseW is None:                     # (lseW unused by the loss)
+            dlseW = torch.zeros(desc.T, desc.B, device=ctx.filt["Fm"].device)
         f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b = ctx.saved
         ov = getattr(desc, "_ov", None)
 

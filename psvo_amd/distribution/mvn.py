@@ -66,4 +66,8 @@ class tf_mvn(nn.Module):
         return self.get_mvn(Input).log_prob(output)
 
     def mean(self, Input, name=None):
-        return self.get_mvn(Input).mean()
+        # (mvn.py:104-117 builds the distribution and takes its mean: the scale plays no part, so its four small
+        #  kernels are not launched -- the hoisted networks call this several times per step)
+        mu, sigma = self.transformation.transform(Input)
+        assert sigma is None
+        return mu

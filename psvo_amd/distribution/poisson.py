@@ -31,4 +31,5 @@ class tf_poisson(nn.Module):
         return self.get_poisson(Input).log_prob(output)
 
     def mean(self, Input, name=None):
-        return self.get_poisson(Input).mean()
+        lambdas, _ = self.transformation.transform(Input)
+        return torch.nn.functional.softplus(lambdas) + 1e-6
