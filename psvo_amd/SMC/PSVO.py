@@ -73,7 +73,9 @@ class PSVO(SVO):
         u_b, sel_in = noise.get("u_b"), noise.get("sel_b")
         if u_b is None and sel_in is None:
             u_b = self._rand(T, B, N, device=dev)
-        obs_TB = obs.transpose(0, 1).contiguous().float()
+        obs_TB = getattr(self, "_obs_TB", None)                                  # cached by SMC() for this batch
+        if obs_TB is None or obs_TB.shape[:2] != (T, B):
+            obs_TB = obs.transpose(0, 1).contiguous().float()
 
         # one opaque autograd node: psvo_bsim_forward / psvo_bsim_backward
         desc = self._desc(M)

@@ -62,7 +62,9 @@ class PSVOwR(PSVO):
         u_r, anc_in = noise.get("u_r"), noise.get("anc_r")
         if u_r is None and anc_in is None:
             u_r = self._rand(T, B, N, device=dev)
-        obs_TB = obs.transpose(0, 1).contiguous().float()
+        obs_TB = getattr(self, "_obs_TB", None)                                  # cached by SMC() for this batch
+        if obs_TB is None or obs_TB.shape[:2] != (T, B):
+            obs_TB = obs.transpose(0, 1).contiguous().float()
 
         desc = self._desc(M)
         gb = (self._gbuf(model.f_tran), self._gbuf(model.g_tran), self._gbuf(model.q1_inv_tran))

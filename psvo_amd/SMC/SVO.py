@@ -107,11 +107,17 @@ class SVO:
             fm0, fsig0 = m0, sig0                                             # f_0 is q0's own density
         else:
             fm0, fsig0 = self.f.mean(preprocessed_X0), self._sigma(self.f)    # SVO.py:91-92
+        obs_TB = obs.transpose(0, 1).contiguous().float()
+        self._obs_TB = obs_TB                                                  # (reused by the backward simulation)
         mu2 = sig_q2 = None
         if model.use_2_q:
-            mu2 = self.q2.mean(preprocessed_obs).transpose(0, 1).contiguous()  # (T, B, Dx)
+            if preprocessed_obs is obs:
+                # raw observations as features (AESMC / IWAE / PSVO): rows in (T, B) order give mu2 in the kernels' layout
+                # directly -- no transposed copy of the output, none of its gradient
+                mu2 = self.q2.mean(obs_TB)                                     # (T, B, Dx)
+            else:
+                mu2 = self.q2.mean(preprocessed_obs).transpose(0, 1).contiguous()
             sig_q2 = self._sigma(self.q2)
-        obs_TB = obs.transpose(0, 1).contiguous().float()
 
         eps = noise.get("eps_f")
         if eps is None:

@@ -204,9 +204,10 @@ class BsimFunction(torch.autograd.Function):
         gg = none4 if gb[1] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
         gq = none4 if gb[2] is not None else ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
         dFm, dlogW = r["dFm"], r["dlogW"]
+        ops.sum_chain_rows(r, desc.T, desc.B, Dx)       # (one reduction for d bmu2 / d minit / d imean)
         return (None, None, None, None, None, dFm, dlogW, None) + tuple(gf) + tuple(gg) + tuple(gq) + (
-            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_rows"].sum(-1),
-            r["dminit_rows"].sum(-1), r["dsig_init"], r["dimean_rows"].sum(-1), r["disig"])
+            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2"],
+            r["dminit"], r["dsig_init"], r["dimean"], r["disig"])
 
 
 class BsimWRFunction(torch.autograd.Function):
@@ -262,9 +263,10 @@ class BsimWRFunction(torch.autograd.Function):
         gf = none4 if gb[0] is not None else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
         gg = none4 if gb[1] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
         gq = none4 if gb[2] is not None else ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
+        ops.sum_chain_rows(r, desc.T, desc.B, Dx)
         return (None,) * 7 + (r["dFm"], r["dlogW"], r["dlse"]) + tuple(gf) + tuple(gg) + tuple(gq) + (
-            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2_rows"].sum(-1),
-            r["dminit_rows"].sum(-1), r["dsig_init"], r["dimean_rows"].sum(-1), r["disig"])
+            r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2"],
+            r["dminit"], r["dsig_init"], r["dimean"], r["disig"])
 
 
 class RowsMLPFunction(torch.autograd.Function):

@@ -379,6 +379,27 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
     return out
 
 
+def _chain_rows(out, z, T, B, Dx, N):
+    """per-chain rows of d bmu2 (T,B,Dx,N), d minit and d imean (B,Dx,N) in ONE buffer, so that one reduction over the
+    chains serves all three (they sit on the dependent chain in front of the encoder BPTT)"""
+    rows = z((T + 2) * B * Dx, N)
+    n = T * B * Dx
+    out["chain_rows"] = rows
+    out["dbmu2_rows"] = rows[:n].view(T, B, Dx, N)
+    out["dminit_rows"] = rows[n:n + B * Dx].view(B, Dx, N)
+    out["dimean_rows"] = rows[n + B * Dx:].view(B, Dx, N)
+
+
+def sum_chain_rows(out, T, B, Dx):
+    """d bmu2 (T,B,Dx), d minit, d imean (B,Dx) from the chain rows of bsim_backward / bsimwr_backward.  Called by the
+    autograd node when it returns, i.e. AFTER the weight-gradient launches were enqueued: issued between the kernel and
+    those launches it changes the captured graph's topology, and the hipGraph executor then ran the filter's reverse pass
+    and the weight gradients one after the other (+0.45 ms per replayed step at C*)."""
+    s = out["chain_rows"].sum(-1)
+    n = T * B * Dx
+    out["dbmu2"], out["dminit"], out["dimean"] = s[:n].view(T, B, Dx), s[n:n + B * Dx].view(B, Dx), s[n + B * Dx:].view(B, Dx)
+
+
 def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig,
                   obs, eps_b, bs, dscore, gbufs=None, after_kernel=None, wgrad_stream=None):
     """psvo_bsim_backward + psvo_mlp_wgrad.  `bs` = bsim_forward(..., save=True) outputs."""
@@ -396,9 +417,9 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
     nblk = lib.psvo_bsim_blocks(B, N, M, H, Dx)
     z = lambda *s: _empty(*s, device=dev)
     out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
-           "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N), "dbmu2_rows": z(T, B, Dx, N),
-           "dminit_rows": z(B, Dx, N), "dimean_rows": z(B, Dx, N),
+           "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N),
            "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx)}
+    _chain_rows(out, z, T, B, Dx, N)
     sacc = z(B, nblk, lib.psvo_bsim_acc_size(Dx, Dy))
     _mark("psvo_bsim_backward", 0)
     st = lib.psvo_bsim_backward(
@@ -490,9 +511,9 @@ def bsimwr_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, 
     K = lib.psvo_bsimwr_blocks(B, N, M)
     out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
            "dFm_part": z(T, B, K, Dx, N), "dlogW_part": z(T, B, K, N), "dlse_part": z(T, B, K),
-           "dbmu2_rows": z(T, B, Dx, N), "dminit_rows": z(B, Dx, N), "dimean_rows": z(B, Dx, N),
            "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx),
            "ws": z(lib.psvo_bsimwr_bwd_ws_floats(B, T, N, Dx))}
+    _chain_rows(out, z, T, B, Dx, N)
     sacc = z(B, K, lib.psvo_bsim_acc_size(Dx, Dy))
     _mark("psvo_bsimwr_backward", 0)
     st = lib.psvo_bsimwr_backward(
