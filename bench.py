@@ -170,10 +170,11 @@ def main():
     ap.add_argument("--workload", default="C*", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
-                    help="replay the step as one captured hipGraph (default): the launching Python thread needs "
-                         "~2.7 ms per C* step and more than the GPU time of the smaller workloads, and its speed "
-                         "varies with the host; eager issue is the fallback if capture fails")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay the step as one captured hipGraph: the launching Python thread needs ~2.7 ms per C* "
+                         "step and more than the GPU time of the smaller workloads, and its speed varies with the host.  "
+                         "Default (neither flag): both ways are calibrated on a few untimed steps and the faster one "
+                         "runs the timed region; eager issue is also the fallback if capture fails")
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="issue every launch eagerly")
     ap.add_argument("--cpu-sample-T", type=int, default=40)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -256,7 +257,7 @@ def main():
         dp.all_reduce_sum_(flat.grad)
         opt.step(lr, world_size=world)
 
-    use_graph, graph_note = args.graph, None
+    use_graph, graph_note = (args.graph is not False), None
     eager_step = train_step if args.mode == "train" else fwd_step
     step = eager_step
     if use_graph:
@@ -297,6 +298,19 @@ def main():
             el = float(t.item())
         return el, z
 
+    if use_graph and args.graph is None:
+        # Neither --graph nor --no-graph: replay takes the launching thread out of the loop (decisive on a slow host and
+        # for the small workloads), but the hipGraph executor's own scheduling of the step's three branches can cost a few
+        # per cent against eager issue from a fast host.  Both are timed on a few untimed steps (max over ranks, so every
+        # rank takes the same decision) and the faster one runs the timed region.
+        def quick(fn, n=10):
+            for _ in range(5):
+                fn()
+            return timed(fn, n, False)[0] / n
+        t_graph, t_eager = quick(step), quick(eager_step)
+        if t_eager < 0.985 * t_graph:
+            use_graph, step = False, eager_step
+            graph_note = "chosen by calibration (%.3f ms against %.3f ms replayed)" % (1e3 * t_eager, 1e3 * t_graph)
     for _ in range(args.warmup):
         z = step()
     # the timed region carries no instrumentation; the per-kernel HIP events (two per native launch) are
@@ -379,7 +393,8 @@ def main():
                                 if args.mode == "train" else "objective evaluation (ELBO + smoothed trajectories)"),
                        "global_batch": B * world, "parallelism": "dp%d (batch of sequences sharded)" % world,
                        "elbo": elbo, "forward_only_particle_steps_per_s": other,
-                       "launch": "hipGraph replay" if use_graph else ("eager" + ("; " + graph_note if graph_note else "")),
+                       "launch": ("hipGraph replay" + ("" if args.graph else " (calibrated against eager issue)")) if use_graph
+                                 else ("eager" + ("; " + graph_note if graph_note else "")),
                        "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())},
                        "native_timeline_ms": timeline},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

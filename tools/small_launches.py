@@ -1,3 +1,9 @@
+"""Diagnostic: which PyTorch ops (each one a small kernel on the step's critical streams) a C* training step still issues
+around the native launches, by call site.  This is how the unused scale computations of the hoisted means (20 launches
+per step) and the zero-filled gradients of the bsim nodes' constant outputs were found.
+
+    python tools/small_launches.py          (GPU box)
+"""
 import os, sys, collections, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
