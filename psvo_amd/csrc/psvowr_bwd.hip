@@ -660,7 +660,9 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
     void* kargs[] = {(void*)&args};
     const void* fn = NTB <= 256 ? (const void*)psvowr_bwd_kernel<DX, DY, H, M, 256>
                                 : (const void*)psvowr_bwd_kernel<DX, DY, H, M, 512>;
-    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(K, a.B), dim3(NTB), kargs, lds, stream);
+    // (K == 1: no cross-workgroup exchange, so no residency requirement -- see psvowr_fwd.hip)
+    const hipError_t e = K > 1 ? hipLaunchCooperativeKernel(fn, dim3(K, a.B), dim3(NTB), kargs, lds, stream)
+                               : hipLaunchKernel(fn, dim3(K, a.B), dim3(NTB), kargs, lds, stream);
     if (e != hipSuccess) {
         g_last_hip_error = e;
         (void)hipGetLastError();

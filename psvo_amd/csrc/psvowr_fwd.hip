@@ -516,10 +516,13 @@ static int launch_wr_fwd(const WrArgs& a, hipStream_t stream) {
     void* kargs[] = {(void*)&args};
     const dim3 grid(K, a.B), block(NTB);
     hipError_t e;
-    if (NTB > 256)
-        e = hipLaunchCooperativeKernel((const void*)psvowr_fwd_kernel<DX, DY, H, M, 1024>, grid, block, kargs, lds, stream);
-    else
-        e = hipLaunchCooperativeKernel((const void*)psvowr_fwd_kernel<DX, DY, H, M, 256>, grid, block, kargs, lds, stream);
+    const void* fn = NTB > 256 ? (const void*)psvowr_fwd_kernel<DX, DY, H, M, 1024>
+                               : (const void*)psvowr_fwd_kernel<DX, DY, H, M, 256>;
+    // a cluster (K > 1) needs all its workgroups resident: cooperative launch.  K == 1 (many sequences, or few chains)
+    // has no cross-workgroup exchange -- a workgroup only reads back its own words -- so the grid may exceed what fits
+    // on the device at once, which a cooperative launch would refuse.
+    if (K > 1) e = hipLaunchCooperativeKernel(fn, grid, block, kargs, lds, stream);
+    else e = hipLaunchKernel(fn, grid, block, kargs, lds, stream);
     if (e != hipSuccess) {
         g_last_hip_error = e;
         (void)hipGetLastError();

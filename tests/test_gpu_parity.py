@@ -400,3 +400,22 @@ def test_psvowr_step_replays_from_hipgraph(built_lib):
         assert torch.isfinite(flat.grad).all()
         assert (flat.grad - g_e).abs().max() <= 1e-5 * float(g_e.abs().max())
     smc.check_exchange()
+
+
+def test_psvowr_many_sequences(built_lib):
+    """More sequences than compute units: one workgroup per sequence (cluster size 1), launched as an ordinary kernel
+    (nothing is exchanged between workgroups, so the grid need not be resident at once, which a cooperative launch would
+    insist on).  ELBO, trajectories and cross-chain ancestors against the oracle; no exchange poll may time out."""
+    B = 600
+    FLAGS, model, smc, obs, noise = _setup("PSVOwR", B, 3, 24, 4, 2, 1, 16, True, True, seed=13)
+    from psvo_amd import ops
+    assert ops._lib.load().psvo_bsimwr_blocks(B, 24, 4) == 1
+    with torch.no_grad():
+        z, log = smc.get_log_ZSMC(obs.float().cuda(), None, noise=Hh.noise_to_hip(noise, "cuda"))
+    torch.cuda.synchronize()
+    smc.check_exchange()
+    assert torch.isfinite(z) and torch.isfinite(log["Xs"]).all()
+    z_ref, ref = Hh.run_oracle(model, FLAGS, "PSVOwR", obs, noise)
+    assert abs(float(z) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+    assert torch.allclose(log["Xs"].double().cpu(), ref["Xs"], atol=2e-4, rtol=1e-5)
+    assert (log["bsim"]["anc"].permute(0, 2, 1).cpu().long() == ref["idx_r"]).all()
