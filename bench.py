@@ -36,6 +36,7 @@ WORKLOADS = {
     "C4": ("PSVO", 32, 200, 256, 2, 1, 16, 32, 32),
     "C5": ("PSVO", 8, 1000, 512, 4, 1, 16, 32, 32),
     "C*wR": ("PSVOwR", 32, 200, 128, 2, 1, 16, 32, 32),     # C* sizes under the PSVOwR objective (not a headline line)
+    "tiny": ("PSVO", 4, 12, 32, 2, 1, 8, 32, 8),            # launcher / multi-rank rehearsals in the tests (not a bench line)
 }
 FP32_PEAK_TFLOPS = 157.3     # MI355X f32 vector peak == f32-input MFMA dense peak (MI355X_MICROARCH.md)
 EXP_PEAK = 9.8e12            # transcendental quarter rate, exp/s
@@ -162,6 +163,58 @@ def elbo_vs_oracle(wl, P, obs_cpu, sample_T, device, threads):
                       "noise, fp64 PyTorch-CPU oracle vs fp32 HIP path (in-kernel multinomial draws)" % (sample_T, T)}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` given as it stands (no torchrun around it): start the N ranks ourselves, one per GPU,
+    exactly as the driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py ...`), BEFORE this process has made any GPU call -- it stays a plain launcher: the children
+    inherit stdout, so rank 0's JSON line is the only line on it, and their exit code is ours."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def plumbing_only(args):
+    """--plumbing-only: the multi-rank skeleton of the bench without the hot path (which needs an MI355X and has no CPU
+    fallback): rendezvous, barrier, the flat-gradient all-reduce on a buffer of the model's size, max-over-ranks timing and
+    rank 0's single JSON line.  Used by the CPU tests (gloo) to cover launching and relaying; never a bench result."""
+    from psvo_amd import dp
+    rank, world = dp.init(backend=os.environ.get("PSVO_DIST_BACKEND", "gloo"))
+    flat = torch.full((22426,), float(rank + 1))
+    dist = torch.distributed if world > 1 else None
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g = flat.clone()
+        dp.all_reduce_sum_(g)
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t)
+    ok = bool((g == world * (world + 1) / 2).all())
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing-only (no hot path, not a bench result)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / max(1, args.steps) * 1e3,
+                          "allreduce_ok": ok}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,14 +231,19 @@ def main():
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="issue every launch eagerly")
     ap.add_argument("--cpu-sample-T", type=int, default=40)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))      # (no GPU call has been made in this process)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
-                         % (args.gpus, args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or run `python bench.py --gpus N` "
+                         "without a launcher: it starts its own ranks)" % (args.gpus, world))
+    if args.plumbing_only:
+        raise SystemExit(plumbing_only(args))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the PSVO hot path")
     # one rank per GPU; (rehearsals on a one-GPU box: ranks share the card, PSVO_DIST_BACKEND=gloo)

@@ -121,6 +121,26 @@ def multinomial_idx(log_W, u):
     return cnt.clamp(max=log_W.shape[0] - 1)
 
 
+def draw_distance(log_W, u, idx):
+    """How far each index `idx` is from being the inverse-CDF draw of `multinomial_idx(log_W, u)`: 0 where
+    cdf[idx-1] <= u*total < cdf[idx], else the distance of u*total to that interval divided by total (so an index
+    that differs only because u*total sits within rounding of a CDF edge has a distance of a few ulp).
+    Shapes as in multinomial_idx; returns a tensor of idx's shape."""
+    w = torch.exp(log_W - log_W.max(dim=0, keepdim=True).values)
+    cdf = torch.cumsum(w, dim=0)
+    total = cdf[-1]
+    K = log_W.shape[0]
+    target = u * total
+    ix = idx if u.dim() == log_W.dim() else idx.unsqueeze(0)
+    hi = torch.gather(cdf, 0, ix)
+    lo = torch.where(ix > 0, torch.gather(cdf, 0, (ix - 1).clamp(min=0)), torch.zeros_like(hi))
+    hi = torch.where(ix == K - 1, torch.full_like(hi, float("inf")), hi)
+    if u.dim() != log_W.dim():
+        hi, lo = hi[0], lo[0]
+    d = torch.clamp(lo - target, min=0) + torch.clamp(target - hi, min=0)
+    return d / total
+
+
 def gather_particles(X, idx):
     """tf.gather_nd(X, resample_idx) for sample_size=N -- src/SMC/SVO.py:255-257,295-298.
 
@@ -275,6 +295,8 @@ class OracleSVO:
             return X, idx0.unsqueeze(0)
         if idx is None:
             idx = multinomial_idx(log_W, u)
+        if getattr(self, "draw_log", None) is not None:   # test hook: every categorical draw (logits, uniform, index taken)
+            self.draw_log.append((log_W.detach(), u, idx))
         g = gather_particles if sample_size != () else gather_sub
         if isinstance(X, list):
             return [g(item, idx) for item in X], idx

@@ -69,6 +69,9 @@ class PSVOwR(PSVO):
         desc = self._desc(M)
         gb = (self._gbuf(model.f_tran), self._gbuf(model.g_tran), self._gbuf(model.q1_inv_tran))
         desc._gbufs = gb if all(v is not None for v in gb) else None
+        if getattr(self, "_sticky", None) is None or self._sticky.device != dev:
+            self._sticky = torch.zeros(1, dtype=torch.int32, device=dev)    # exchange time-outs of ALL launches so far
+        desc._sticky = self._sticky
         lseW, bwXanc, bwX, bwW, sel, anc, ws = BsimWRFunction.apply(
             desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, filt["Fm"], filt["logW"], filt["lse"],
             *model.f_tran.hip_params(), *model.g_tran.hip_params(), *model.q1_inv_tran.hip_params(),
@@ -79,8 +82,15 @@ class PSVOwR(PSVO):
         return {"lseW": lseW, "bwXanc": bwXanc, "bwX": bwX, "bwW": bwW, "sel": sel, "anc": anc, "ws": ws}
 
     def check_exchange(self):
-        """Raise if the workgroups of a sequence lost each other in the most recent evaluation (a bounded poll of
-        psvo_bsimwr_forward timed out and the kernel drained with garbage).  Synchronises: called between epochs."""
-        ws = getattr(self, "_last_ws", None)
-        if ws is not None and int(ws[-1:].view(torch.int32)) != 0:
-            raise RuntimeError("psvo_bsimwr_forward: an exchange poll between the workgroups of a sequence timed out")
+        """Raise if the workgroups of a sequence lost each other in ANY evaluation or reverse pass since the last call (a
+        bounded poll of psvo_bsimwr_forward / psvo_bsimwr_backward timed out and the kernel drained with garbage: the
+        objective or its gradients were wrong).  Every launch ORs its flag into one sticky device word, so a time-out in
+        an earlier mini-batch is not erased by the launches after it.  Synchronises: the trainer calls it once an epoch."""
+        sticky = getattr(self, "_sticky", None)
+        if sticky is None:
+            return
+        v = int(sticky.item())
+        if v:
+            sticky.zero_()
+            which = " and ".join(n for b, n in ((1, "psvo_bsimwr_forward"), (2, "psvo_bsimwr_backward")) if v & b)
+            raise RuntimeError("%s: an exchange poll between the workgroups of a sequence timed out" % which)

@@ -210,6 +210,14 @@ class BsimFunction(torch.autograd.Function):
             r["dminit"], r["dsig_init"], r["dimean"], r["disig"])
 
 
+def _note_exchange(desc, ws, bit):
+    """OR the launch's exchange-timeout flag (last word of its workspace, cleared by every launch) into the sticky
+    device word the objective keeps across launches (PSVOwR.check_exchange reads it): bit 1 = forward, bit 2 = reverse."""
+    sticky = getattr(desc, "_sticky", None)
+    if sticky is not None:
+        sticky.bitwise_or_((ws[-1:].view(torch.int32) != 0).to(torch.int32) * bit)
+
+
 class BsimWRFunction(torch.autograd.Function):
     """psvo_bsimwr_forward / psvo_bsimwr_backward (PSVOwR: cross-chain resampling, per-step ELBO).
 
@@ -233,6 +241,7 @@ class BsimWRFunction(torch.autograd.Function):
         bs = ops.bsimwr_forward(desc, filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean,
                                 isig, obs_TB, eps_b, u_b=u_b, u_r=u_r, sel_in=sel_in, anc_in=anc_in, save=need)
         ctx.desc, ctx.filt, ctx.bs = desc, filt, bs
+        _note_exchange(desc, bs["ws"], 1)
         ctx.saved = (f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b)
         ctx.mark_non_differentiable(bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"], bs["ws"])
         ctx.set_materialize_grads(False)      # (else the engine zero-fills a gradient for each of the six constants)
@@ -264,6 +273,7 @@ class BsimWRFunction(torch.autograd.Function):
         gg = none4 if gb[1] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
         gq = none4 if gb[2] is not None else ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
         ops.sum_chain_rows(r, desc.T, desc.B, Dx)
+        _note_exchange(desc, r["ws"], 2)          # (after the weight-gradient launches: see ops.sum_chain_rows)
         return (None,) * 7 + (r["dFm"], r["dlogW"], r["dlse"]) + tuple(gf) + tuple(gg) + tuple(gq) + (
             r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2"],
             r["dminit"], r["dsig_init"], r["dimean"], r["disig"])

@@ -38,11 +38,15 @@ struct WrBwdArgs {
     unsigned* err;                               // error flag: a poll timed out
 };
 
-// words a chain publishes per step (d loss / d bwXanc, Dx <= 4) and the exchange workspace: a two-step ring
-// [2][B][N][kWbWords] of tagged 64-bit words {bits(value), tag}, then two 32-bit words whose last one is the error flag
-// (protocol and the two-slot argument: psvowr_fwd.hip)
+// words a chain publishes per step (d loss / d bwXanc, Dx <= 4) and the exchange workspace: ONE SLOT PER STEP,
+// [T][B][N][kWbWords] tagged 64-bit words {bits(value), tag}, then two 32-bit words whose last one is the error flag.
+// The forward kernel gets away with a two-slot ring because there every workgroup polls all N chains every step, which
+// bounds the run-ahead of any workgroup to one step.  Here a workgroup polls only the chains whose parent it owns; under
+// weight degeneracy most workgroups own no parent for many steps, nothing holds them back, and in a two-slot ring their
+// publication of step t+1 would overwrite words of step t-1 that a slower workgroup has not polled yet.  With a slot per
+// step a word is written once per launch and never overwritten (26 MB at C*; cleared by the launch's memset).
 constexpr int kWbWords = 4;
-static inline long long wb_ws_floats(int B, int N) { return 2ll * (2ll * B * N * kWbWords) + 2; }
+static inline long long wb_ws_floats(int B, int T, int N) { return 2ll * ((long long)T * B * N * kWbWords) + 2; }
 
 template <int DX, int DY>
 struct WAcc {   // same slots as BAcc in bsim_bwd_impl.h (shares bsim_bwd_finalize's algebra)
@@ -458,7 +462,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
             SEC(4);   // MLP_f / MLP_g forward + input gradients, row stores
             if (r == 0) {
                 if (t >= 1) {
-                    const unsigned long long* const slot = a.ring + ((size_t)(t & 1) * B + b) * N * kWbWords;
+                    const unsigned long long* const slot = a.ring + ((size_t)t * B + b) * N * kWbWords;
                     const unsigned tag = (unsigned)(t + 1);
                     for (int k = tid; k < N; k += NTB) {
                         const int p = a.anc[tb * N + k];
@@ -536,7 +540,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
                     if (!last)     // d loss / d bwXanc_{t+1}[n], polled by the parents' owners at step t+1 (tag t+2)
-                        __hip_atomic_store(a.ring + (((size_t)((t + 1) & 1) * B + b) * N + n) * kWbWords + d,
+                        __hip_atomic_store(a.ring + (((size_t)(t + 1) * B + b) * N + n) * kWbWords + d,
                                            ((unsigned long long)(unsigned)(t + 2) << 32) |
                                                (unsigned long long)__float_as_uint(dxp[d]),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -654,7 +658,7 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
     // tags of an earlier launch must not be mistaken for this one's: clear the ring and the error flag
-    if (hipMemsetAsync(a.ring, 0, sizeof(float) * (size_t)wb_ws_floats(a.B, a.N), stream) != hipSuccess)
+    if (hipMemsetAsync(a.ring, 0, sizeof(float) * (size_t)wb_ws_floats(a.B, a.T, a.N), stream) != hipSuccess)
         return launch_status();
     WrBwdArgs args = a;
     void* kargs[] = {(void*)&args};
@@ -706,8 +710,8 @@ static int wb_dispatch_dy(const WrBwdArgs& a, const WrBwdOut& o, int Dy, int H, 
 }  // namespace psvo
 
 extern "C" long long psvo_bsimwr_bwd_ws_floats(int B, int T, int N, int Dx) {
-    (void)T; (void)Dx;
-    return psvo::wb_ws_floats(B, N);
+    (void)Dx;
+    return psvo::wb_ws_floats(B, T, N);
 }
 
 extern "C" int psvo_bsimwr_backward(
@@ -741,7 +745,7 @@ extern "C" int psvo_bsimwr_backward(
     a.dbmu2_rows = dbmu2_rows; a.dminit_rows = dminit_rows; a.dimean_rows = dimean_rows; a.sacc = sacc;
     if (reinterpret_cast<uintptr_t>(ws) & 7u) return PSVO_ERR_INVALID;      // 64-bit words
     a.ring = reinterpret_cast<unsigned long long*>(ws);
-    a.err = reinterpret_cast<unsigned*>(ws + wb_ws_floats(desc->B, desc->N) - 1);
+    a.err = reinterpret_cast<unsigned*>(ws + wb_ws_floats(desc->B, desc->T, desc->N) - 1);
     WrBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {

@@ -1,14 +1,15 @@
-"""trainer -- mirror of reference src/trainer.py:21-395 (public surface: constructor,
-init_data_saving, train, evaluate, evaluate_R_square, adjust_lr, saving_feed_dict).
+"""trainer -- the reference's training driver (src/trainer.py:21-395) for the MI355X path: same public surface
+(constructor, init_data_saving, train, evaluate, evaluate_R_square, adjust_lr, saving_feed_dict, the metric /
+trajectory pickles and their keys) and the same schedule semantics, written for this stack.
 
-TensorFlow graph/session plumbing has no equivalent: `fetches` are names ("log_ZSMC", "Xs",
-"y_hat", "y") instead of graph tensors and feed dicts are keyed by model.obs / model.hidden
-("obs" / "hidden").  Matplotlib output (quiver, R-square plots) is presentation only and not
-built; the pickled per-epoch artefacts keep the reference's keys.
+TensorFlow graph/session plumbing has no equivalent: `fetches` are names ("log_ZSMC", "Xs", "y_hat", "y") instead of
+graph tensors and feed dicts are keyed by model.obs / model.hidden ("obs" / "hidden").  Matplotlib output (quiver,
+R-square plots) is presentation only and not built.
 
-Data parallelism (new relative to the reference): with W ranks every
-mini-batch of FLAGS.batch_size sequences is sharded FLAGS.batch_size / W per rank; one flat
-all-reduce of the gradient per step, identical Adam update on every rank.
+Data parallelism (new relative to the reference): with W ranks every mini-batch of
+FLAGS.batch_size sequences is sharded FLAGS.batch_size / W per rank; one flat all-reduce of the gradient per step,
+identical Adam update on every rank (checked bit for bit every print_freq epochs); evaluation batches are dealt
+round-robin over the ranks and gathered.
 """
 import math
 import os
@@ -33,25 +34,35 @@ def _shuffle(*arrays):
     return tuple(a[perm] for a in arrays)
 
 
+def _r_square(y_hat, y):
+    """1 - SS_res / SS_tot with the total sum of squares taken around the mean over the evaluation set (axis 0), per
+    time step and feature -- the reference's definition (trainer.py:325-329)."""
+    resid = y_hat - y
+    centred = y - y.mean(axis=0, keepdims=True)
+    return 1.0 - float(np.square(resid).sum()) / float(np.square(centred).sum())
+
+
+def _collate(per_batch, keepdims):
+    """values of ONE fetch over the evaluation batches -> one array (or list of arrays for a list-valued fetch)"""
+    first = per_batch[0]
+    if isinstance(first, np.ndarray):
+        return np.stack(per_batch) if keepdims else np.concatenate(per_batch)
+    if isinstance(first, list):                       # k-step predictions: one array per horizon
+        return [np.concatenate(col) for col in zip(*per_batch)]
+    return np.asarray(per_batch)                      # scalars (log_ZSMC of each batch)
+
+
 class trainer:
+    # schedule state, reference names (trainer.py:63-80): bestCost = index of the best validation ELBO so far,
+    # *_count = evaluations since it improved
     def __init__(self, model, SMC, FLAGS):
-        self.model = model
-        self.SMC = SMC
-        self.FLAGS = FLAGS
-
-        self.Dx = self.FLAGS.Dx
-        self.Dy = self.FLAGS.Dy
-        self.time = self.FLAGS.time
-        self.n_particles = self.FLAGS.n_particles
-
-        self.MSE_steps = self.FLAGS.MSE_steps
-
+        self.model, self.SMC, self.FLAGS = model, SMC, FLAGS
+        for name in ("Dx", "Dy", "time", "n_particles", "MSE_steps"):
+            setattr(self, name, getattr(FLAGS, name))
         self.save_res = False
         self.draw_quiver_during_training = False
-
         self.init_placeholder()
         self.init_training_param()
-
         self.device = next(model.parameters()).device
         self.flat = None
         self.optimizer = None
@@ -61,41 +72,22 @@ class trainer:
         self.hidden = self.model.hidden
 
     def init_training_param(self):
-        self.batch_size = self.FLAGS.batch_size
-        self.lr = self.FLAGS.lr
-        self.epoch = self.FLAGS.epoch
-
-        # early stopping
-        self.early_stop_patience = self.FLAGS.early_stop_patience
-        self.bestCost = 0
-        self.early_stop_count = 0
-
-        # lr auto decreasing
-        self.lr_reduce_factor = self.FLAGS.lr_reduce_factor
-        self.lr_reduce_patience = self.FLAGS.lr_reduce_patience
-        self.min_lr = self.FLAGS.min_lr
-        self.lr_reduce_count = 0
+        F = self.FLAGS
+        self.batch_size, self.lr, self.epoch = F.batch_size, F.lr, F.epoch
+        self.early_stop_patience = F.early_stop_patience
+        self.lr_reduce_factor, self.lr_reduce_patience, self.min_lr = F.lr_reduce_factor, F.lr_reduce_patience, F.min_lr
+        self.bestCost = self.early_stop_count = self.lr_reduce_count = 0
 
     def init_data_saving(self, RLT_DIR):
-        self.save_res = True
-        self.RLT_DIR = RLT_DIR
-        self.save_trajectory = self.FLAGS.save_trajectory
-        self.save_y_hat = self.FLAGS.save_y_hat
-        self.saving_num = self.FLAGS.saving_num
-
-        # metrics
-        self.log_ZSMC_trains = []
-        self.log_ZSMC_tests = []
-        self.R_square_trains = []
-        self.R_square_tests = []
-
-        # epoch data (trajectory, y_hat and quiver lattice)
-        epoch_data_DIR = self.RLT_DIR.split("/")
-        epoch_data_DIR.insert(epoch_data_DIR.index("rslts") + 1, "epoch_data")
-        self.epoch_data_DIR = "/".join(epoch_data_DIR)
-
-        self.save_tensorboard = self.FLAGS.save_tensorboard
-        self.save_model = self.FLAGS.save_model
+        F = self.FLAGS
+        self.save_res, self.RLT_DIR = True, RLT_DIR
+        self.save_trajectory, self.save_y_hat, self.saving_num = F.save_trajectory, F.save_y_hat, F.saving_num
+        self.save_tensorboard, self.save_model = F.save_tensorboard, F.save_model
+        self.log_ZSMC_trains, self.log_ZSMC_tests, self.R_square_trains, self.R_square_tests = [], [], [], []
+        # per-epoch artefacts live in a sibling tree: .../rslts/<...> -> .../rslts/epoch_data/<...> (trainer.py:93-95)
+        parts = RLT_DIR.split("/")
+        at = parts.index("rslts") + 1
+        self.epoch_data_DIR = "/".join(parts[:at] + ["epoch_data"] + parts[at:])
 
     # ------------------------------------------------------------------------------------------
     def _to_dev(self, a):
@@ -168,183 +160,156 @@ class trainer:
         self.optimizer = TFAdam(self.flat)                       # tf.train.AdamOptimizer(lr), trainer.py:117
         log = {"Xs": "Xs", "y_hat": "y_hat"}
         verbose = dp.rank() == 0
+        check_exchange = getattr(self.SMC, "check_exchange", None)   # (PSVOwR: sticky flag of the kernels' bounded polls)
 
         for i in range(self.epoch):
             start = time.time()
-
             if i == 0:
                 self.evaluate_and_save_metrics(i)
 
-            # training
             obs_train, hidden_train = _shuffle(obs_train, hidden_train)
             for j in range(0, len(obs_train), self.batch_size):
                 self.train_step(obs_train[j:j + self.batch_size], hidden_train[j:j + self.batch_size], self.lr)
+            if check_exchange is not None:
+                check_exchange()                                 # every epoch: a timed-out exchange means garbage gradients
 
             if (i + 1) % print_freq == 0:
-                check = getattr(self.SMC, "check_exchange", None)      # (PSVOwR: the kernels' bounded polls)
-                if check is not None:
-                    check()
+                if not dp.replicas_in_sync(self.flat.flat):
+                    raise RuntimeError("data-parallel replicas diverged (parameters differ between ranks)")
                 try:
                     self.evaluate_and_save_metrics(i)
                     self.adjust_lr(i, print_freq)
                 except StopTraining:
                     break
-
                 if self.save_res:
-                    self.saving_feed_dict = {self.obs: obs_test[0:self.saving_num],
-                                             self.hidden: hidden_test[0:self.saving_num]}
-                    if verbose and (self.save_trajectory or self.save_y_hat):
-                        Xs_val = self.evaluate("Xs", self.saving_feed_dict, average=False)
-                        if self.save_trajectory:
-                            with open(self.epoch_data_DIR + "trajectory_{}.p".format(i + 1), "wb") as f:
-                                pickle.dump({"Xs": Xs_val}, f)
-                        if self.save_y_hat:
-                            y_hat_val = self.evaluate("y_hat", self.saving_feed_dict, average=False)
-                            with open(self.epoch_data_DIR + "y_hat_{}.p".format(i + 1), "wb") as f:
-                                pickle.dump({"y_hat": y_hat_val}, f)
-
-            end = time.time()
+                    self._save_epoch_samples(i + 1, obs_test, hidden_test, verbose)
             if verbose:
-                print("epoch {:<4} took {:.3f} seconds".format(i + 1, end - start))
+                print("epoch {:<4} took {:.3f} seconds".format(i + 1, time.time() - start))
 
         if verbose:
             print("finished training...")
-
-        metrics = {"log_ZSMC_trains": self.log_ZSMC_trains,
-                   "log_ZSMC_tests": self.log_ZSMC_tests,
-                   "R_square_trains": self.R_square_trains,
-                   "R_square_tests": self.R_square_tests} if self.save_res else {}
+        metrics = {}
+        if self.save_res:
+            metrics = {k: getattr(self, k) for k in ("log_ZSMC_trains", "log_ZSMC_tests", "R_square_trains", "R_square_tests")}
         return metrics, log
+
+    def _save_epoch_samples(self, epoch, obs_test, hidden_test, write):
+        """trajectory_<epoch>.p / y_hat_<epoch>.p for the first saving_num held-out sequences (trainer.py:170-186)"""
+        self.saving_feed_dict = {self.obs: obs_test[:self.saving_num], self.hidden: hidden_test[:self.saving_num]}
+        for flag, fetch, stem in ((self.save_trajectory, "Xs", "trajectory"), (self.save_y_hat, "y_hat", "y_hat")):
+            if not flag:
+                continue
+            val = self.evaluate(fetch, self.saving_feed_dict, average=False)      # (collective: every rank takes part)
+            if write:
+                with open(self.epoch_data_DIR + "{}_{}.p".format(stem, epoch), "wb") as f:
+                    pickle.dump({fetch: val}, f)
 
     def close_session(self):
         pass
 
     def evaluate_and_save_metrics(self, iter_num, y_hat_N_BxTxDy=None, y_N_BxTxDy=None):
-        log_ZSMC_train, y_hat_train, y_train = \
-            self.evaluate(["log_ZSMC", "y_hat", "y"], {self.obs: self.obs_train, self.hidden: self.hidden_train})
-        log_ZSMC_test, y_hat_test, y_test = \
-            self.evaluate(["log_ZSMC", "y_hat", "y"], {self.obs: self.obs_test, self.hidden: self.hidden_test})
-
-        log_ZSMC_train, log_ZSMC_test = np.mean(log_ZSMC_train), np.mean(log_ZSMC_test)
-        R_square_train = self.evaluate_R_square(y_hat_train, y_train)
-        R_square_test = self.evaluate_R_square(y_hat_test, y_test)
-
-        # every rank must take the same early-stop / lr decisions: rank 0's numbers are authoritative
-        if dp.world_size() > 1:
-            import torch.distributed as dist
-            box = [(log_ZSMC_train, log_ZSMC_test, R_square_train, R_square_test)]
-            dist.broadcast_object_list(box, src=0)
-            log_ZSMC_train, log_ZSMC_test, R_square_train, R_square_test = box[0]
+        """ELBO and k-step R-square on the training and held-out sets; appended to the histories and pickled as
+        metric_<iter>.p with the reference's keys (trainer.py:201-241).  A non-finite training ELBO stops training."""
+        fetches = ["log_ZSMC", "y_hat", "y"]
+        m = {}
+        for split, obs, hid in (("train", self.obs_train, self.hidden_train), ("test", self.obs_test, self.hidden_test)):
+            elbos, y_hat, y = self.evaluate(fetches, {self.obs: obs, self.hidden: hid})
+            m["log_ZSMC_" + split] = np.mean(elbos)
+            m["R_square_" + split] = self.evaluate_R_square(y_hat, y)
 
         if dp.rank() == 0:
             print()
             print("iter", iter_num + 1)
-            print("Train log_ZSMC: {:>7.3f}, valid log_ZSMC: {:>7.3f}".format(log_ZSMC_train, log_ZSMC_test))
-            print("Train, Valid k-step Rsq:\n", R_square_train, "\n", R_square_test)
+            print("Train log_ZSMC: {:>7.3f}, valid log_ZSMC: {:>7.3f}".format(m["log_ZSMC_train"], m["log_ZSMC_test"]))
+            print("Train, Valid k-step Rsq:\n", m["R_square_train"], "\n", m["R_square_test"])
 
-        if not math.isfinite(log_ZSMC_train):
+        if not math.isfinite(m["log_ZSMC_train"]):
             print("Nan in log_ZSMC, stop training")
             raise StopTraining()
 
         if self.save_res:
-            self.log_ZSMC_trains.append(log_ZSMC_train)
-            self.log_ZSMC_tests.append(log_ZSMC_test)
-            self.R_square_trains.append(R_square_train)
-            self.R_square_tests.append(R_square_test)
-
+            for key, val in m.items():
+                getattr(self, key + "s").append(val)
             if dp.rank() == 0:
-                if not os.path.exists(self.epoch_data_DIR):
-                    os.makedirs(self.epoch_data_DIR)
-                metric_dict = {"log_ZSMC_train": log_ZSMC_train,
-                               "log_ZSMC_test": log_ZSMC_test,
-                               "R_square_train": R_square_train,
-                               "R_square_test": R_square_test}
+                os.makedirs(self.epoch_data_DIR, exist_ok=True)
                 with open(self.epoch_data_DIR + "metric_{}.p".format(iter_num + 1), "wb") as f:
-                    pickle.dump(metric_dict, f)
-
-        return log_ZSMC_train, log_ZSMC_test, R_square_train, R_square_test
+                    pickle.dump(dict(m), f)
+        return m["log_ZSMC_train"], m["log_ZSMC_test"], m["R_square_train"], m["R_square_test"]
 
     def adjust_lr(self, iter_num, print_freq):
-        # determine whether should decrease lr or even stop training
-        if self.bestCost != np.argmax(self.log_ZSMC_tests):
-            self.early_stop_count = 0
-            self.lr_reduce_count = 0
-            self.bestCost = np.argmax(self.log_ZSMC_tests)
-
-        if dp.rank() == 0:
+        """Plateau schedule on the held-out ELBO history (trainer.py:244-270): whenever the best evaluation moves, both
+        patience counters restart; while the latest evaluation is not the best one, each counter advances, training stops
+        when early_stop_count * print_freq hits early_stop_patience exactly, and the learning rate is multiplied by
+        lr_reduce_factor (floored at min_lr) each time lr_reduce_count * print_freq hits lr_reduce_patience."""
+        history = self.log_ZSMC_tests
+        best, latest = int(np.argmax(history)), len(history) - 1
+        if best != self.bestCost:
+            self.bestCost, self.early_stop_count, self.lr_reduce_count = best, 0, 0
+        talk = dp.rank() == 0
+        if talk:
             print("best valid cost on iter: {}\n".format(self.bestCost * print_freq))
 
-        if self.bestCost != len(self.log_ZSMC_tests) - 1:
+        if best != latest:
             self.early_stop_count += 1
-            if self.early_stop_count * print_freq == self.early_stop_patience:
-                print("valid cost not improving. stopping training...")
-                raise StopTraining()
-
             self.lr_reduce_count += 1
+            if self.early_stop_count * print_freq == self.early_stop_patience:
+                if talk:
+                    print("valid cost not improving. stopping training...")
+                raise StopTraining()
             if self.lr_reduce_count * print_freq == self.lr_reduce_patience:
                 self.lr_reduce_count = 0
                 self.lr = max(self.lr * self.lr_reduce_factor, self.min_lr)
-                print("valid cost not improving. reduce learning rate to {}".format(self.lr))
-
-        if self.save_model and dp.rank() == 0:
-            if not os.path.exists(self.RLT_DIR + "model/"):
-                os.makedirs(self.RLT_DIR + "model/")
-            if self.bestCost == len(self.log_ZSMC_tests) - 1:
-                print("Test log_ZSMC improves to {}, save model".format(self.log_ZSMC_tests[-1]))
-                torch.save(self.model.state_dict(), self.RLT_DIR + "model/model_epoch_{}.pt".format(iter_num + 1))
+                if talk:
+                    print("valid cost not improving. reduce learning rate to {}".format(self.lr))
+        elif self.save_model and talk:
+            os.makedirs(self.RLT_DIR + "model/", exist_ok=True)
+            print("Test log_ZSMC improves to {}, save model".format(history[-1]))
+            torch.save(self.model.state_dict(), self.RLT_DIR + "model/model_epoch_{}.pt".format(iter_num + 1))
 
     # ------------------------------------------------------------------------------------------
     def _run(self, names, obs, hidden):
         """one forward evaluation of a batch (sess.run(fetches) of the reference)"""
         with torch.no_grad():
-            log_ZSMC, log = self.SMC.get_log_ZSMC(self._to_dev(obs), self._to_dev(hidden))
+            obs_d = self._to_dev(obs)
+            log_ZSMC, log = self.SMC.get_log_ZSMC(obs_d, self._to_dev(hidden))
             out = {"log_ZSMC": float(log_ZSMC)}
             if any(n in names for n in ("Xs", "y_hat", "y")):
                 Xs = log["Xs"]
                 out["Xs"] = Xs.contiguous().cpu().numpy()
                 if "y_hat" in names or "y" in names:
-                    y_hat, y = self.SMC.n_step_prediction(self.MSE_steps, Xs, self._to_dev(obs))
+                    y_hat, y = self.SMC.n_step_prediction(self.MSE_steps, Xs, obs_d)
                     out["y_hat"] = [v.cpu().numpy() for v in y_hat]
                     out["y"] = [v.cpu().numpy() for v in y]
         return [out[n] for n in names]
 
     def evaluate(self, fetches, feed_dict_w_batches={}, average=False, keepdims=False):
-        """trainer.py:272-320: evaluate `fetches` across the batches of feed_dict_w_batches."""
+        """Evaluate `fetches` (a name or a list of names) over feed_dict_w_batches in mini-batches of batch_size (a short
+        last batch is evaluated as it is) and join the results: arrays are concatenated over the batch axis (stacked with
+        keepdims), list-valued fetches element-wise, scalars become a vector with one entry per batch; `average` then takes
+        the mean over the leading axis.  Semantics of the reference's trainer.evaluate (trainer.py:272-320).
+        With W ranks the batches are dealt round-robin (batch k to rank k mod W) and gathered, so every rank returns the
+        full result."""
         single = not isinstance(fetches, list)
         names = [fetches] if single else list(fetches)
-        obs_all = feed_dict_w_batches[self.obs]
-        hid_all = feed_dict_w_batches[self.hidden]
-        n_batches = len(obs_all)
-        assert n_batches >= self.batch_size
+        obs_all, hid_all = feed_dict_w_batches[self.obs], feed_dict_w_batches[self.hidden]
+        n = len(obs_all)
+        assert n >= self.batch_size
+        starts = list(range(0, n, self.batch_size))
+        W, r = dp.world_size(), dp.rank()
+        mine = {k: self._run(names, obs_all[s:s + self.batch_size], hid_all[s:s + self.batch_size])
+                for k, s in enumerate(starts) if k % W == r}
+        if W > 1:
+            import torch.distributed as dist
+            parts = [None] * W
+            dist.all_gather_object(parts, mine)
+            mine = {k: v for part in parts for k, v in part.items()}
+        rows = [mine[k] for k in range(len(starts))]
 
-        fetches_list = []
-        for i in range(0, n_batches, self.batch_size):
-            fetches_list.append(self._run(names, obs_all[i:i + self.batch_size], hid_all[i:i + self.batch_size]))
-
-        res = []
-        for i in range(len(names)):
-            if isinstance(fetches_list[0][i], np.ndarray):
-                tmp = np.stack([x[i] for x in fetches_list]) if keepdims else np.concatenate([x[i] for x in fetches_list])
-            elif isinstance(fetches_list[0][i], list):
-                tmp = [np.concatenate([x[i][j] for x in fetches_list]) for j in range(len(fetches_list[0][i]))]
-            else:
-                tmp = np.array([x[i] for x in fetches_list])
-            res.append(tmp)
+        res = [_collate([row[i] for row in rows], keepdims) for i in range(len(names))]
         if average:
-            res = [[np.mean(y, axis=0) for y in x] if isinstance(x, list) else np.mean(x, axis=0) for x in res]
+            res = [[np.mean(a, axis=0) for a in x] if isinstance(x, list) else np.mean(x, axis=0) for x in res]
         return res[0] if single else res
 
     def evaluate_R_square(self, y_hat, y):
-        """trainer.py:322-335"""
-        n_steps = len(y_hat) - 1
-
-        def get_R_square(y_hat_i, y_i):
-            MSE = np.sum((y_hat_i - y_i) ** 2)
-            y_i_mean = np.mean(y_i, axis=0, keepdims=True)
-            y_i_var = np.sum((y_i - y_i_mean) ** 2)
-            return 1 - MSE / y_i_var
-
-        R_square = np.zeros(n_steps + 1)
-        for i, (y_hat_i, y_i) in enumerate(zip(y_hat, y)):
-            R_square[i] = get_R_square(y_hat_i, y_i)
-        return R_square
+        """R-square of the k-step-ahead predictions, k = 0 .. MSE_steps (trainer.py:322-335): one number per horizon"""
+        return np.array([_r_square(np.asarray(p), np.asarray(t)) for p, t in zip(y_hat, y)])

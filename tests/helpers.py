@@ -86,3 +86,38 @@ def fill_from_npz(prefix, x, npz):
     if isinstance(x, (list, tuple)):
         return type(x)(fill_from_npz(prefix + "." + str(i), v, npz) for i, v in enumerate(x))
     return x
+
+
+def hip_indices(log, objective):
+    """the indices the HIP run drew, in the oracle's (T, N, B) layout, keyed as the oracle's teacher-forcing inputs"""
+    out = {}
+    if log["filter"].get("idx") is not None:
+        out["idx_f"] = log["filter"]["idx"].permute(0, 2, 1).cpu().long()
+    if objective in ("PSVO", "PSVOwR"):
+        out["idx_b"] = log["bsim"]["sel"].permute(0, 2, 1).cpu().long()
+    if objective == "PSVOwR":
+        out["idx_r"] = log["bsim"]["anc"].permute(0, 2, 1).cpu().long()
+    return out
+
+
+def replay_with_hip_indices(model, FLAGS, objective, obs, noise, log):
+    """Run the fp64 oracle with the HIP run's own indices teacher-forced (uniforms still supplied) and measure, for every
+    categorical draw of the run, how far the index the kernel took is from the oracle's inverse-CDF draw on the oracle's
+    logits (oracle.draw_distance: 0 = the oracle's own draw; a few ulp = the uniform sits on a CDF edge).
+    Returns (z_ref, ref_log, stats) with stats = dict(draws, off, worst): number of draws, number with a nonzero
+    distance (the genuinely flipped indices), the largest distance (fraction of the total weight)."""
+    P = model.export_reference_layout(torch.float64)
+    o = O.OBJECTIVES[objective](P, oracle_flags(FLAGS, objective))
+    o.draw_log = []
+    nz = dict(noise)
+    nz.update(hip_indices(log, objective))
+    with torch.no_grad():
+        z, ref = o.get_log_ZSMC(obs.double().cpu(), nz)
+    draws = off = 0
+    worst = 0.0
+    for log_W, u, idx in o.draw_log:
+        d = O.draw_distance(log_W, u, idx)
+        draws += d.numel()
+        off += int((d > 0).sum())
+        worst = max(worst, float(d.max()))
+    return z, ref, {"draws": draws, "off": off, "worst": worst}

@@ -20,6 +20,43 @@ def _worker(rank, world, port, q):
         q.put((rank, "error: %r" % (e,)))
 
 
+def _sharded_evaluate_ok(rank, world):
+    """trainer.evaluate deals the evaluation batches round-robin over the ranks and gathers: every rank must return what a
+    single process returns (a stub objective stands in for the HIP path, which needs a GPU)"""
+    import numpy as np
+    from psvo_amd.flags import Flags
+    from psvo_amd.trainer import trainer
+
+    class StubModel(torch.nn.Linear):
+        obs, hidden = "obs", "hidden"
+
+    class StubSMC:
+        calls = 0
+
+        def get_log_ZSMC(self, obs, hidden):
+            StubSMC.calls += 1
+            Xs = (obs[:, :, None, :1] + hidden[:, :, None, :]).expand(-1, -1, 3, -1)
+            return obs.sum() + 2.0 * hidden.sum(), {"Xs": Xs}
+
+        def n_step_prediction(self, n, Xs, obs):
+            x = Xs.mean(2)[..., :1]
+            return [x[:, k:] * (k + 1) for k in range(n + 1)], [obs[:, k:] for k in range(n + 1)]
+    FLAGS = Flags(batch_size=2, time=6, MSE_steps=2)
+    tr = trainer(StubModel(1, 1), StubSMC(), FLAGS)
+    g = np.random.RandomState(5)
+    obs, hid = g.randn(7, 6, 1), g.randn(7, 6, 2)           # 4 batches, the last one short
+    feed = {tr.obs: obs, tr.hidden: hid}
+    z, yh, y, Xs = tr.evaluate(["log_ZSMC", "y_hat", "y", "Xs"], feed)
+    n_mine = StubSMC.calls
+    want_z = np.array([obs[s:s + 2].sum() + 2 * hid[s:s + 2].sum() for s in range(0, 7, 2)])
+    ok = np.allclose(z, want_z, atol=1e-4) and Xs.shape == (7, 6, 3, 2) and len(yh) == 3
+    ok = ok and np.allclose(Xs[:, :, 0], obs + hid, atol=1e-5)
+    ok = ok and all(np.allclose(y[k], obs[:, k:], atol=1e-6) and yh[k].shape == (7, 6 - k, 1) for k in range(3))
+    ok = ok and n_mine == 2                                   # 4 batches over 2 ranks
+    avg = tr.evaluate("log_ZSMC", feed, average=True)
+    return bool(ok and abs(float(avg) - want_z.mean()) < 1e-4)
+
+
 def _worker_body(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from psvo_amd import dp
@@ -87,6 +124,7 @@ def _worker_body(rank, world, port, q):
         ok = False
     except ValueError:
         pass
+    ok = ok and _sharded_evaluate_ok(rank, world)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

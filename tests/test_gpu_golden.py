@@ -61,7 +61,7 @@ def test_golden_vectors(built_lib, name):
     assert np.abs(g - gr).max() <= 2e-3 * max(np.abs(gr).max(), 1e-6) + 1e-6
 
 
-@pytest.mark.parametrize("wl", ["C2", "C*", "C3"])
+@pytest.mark.parametrize("wl", ["C2", "C*", "C3", "C4", "C5"])
 def test_full_size_properties(built_lib, wl):
     """BASELINE.json sizes, where the oracle is too slow: identities that hold at any size"""
     sys.path.insert(0, os.path.dirname(GOLD + "/../.."))
