@@ -232,6 +232,9 @@ def main():
     ap.add_argument("--cpu-sample-T", type=int, default=40)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--bsim-bwd-variant", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="A/B switch of the reverse backward-simulation kernel (psvo_set_tuning, include/psvo_hip.h): "
+                         "0 = v1 butterflies, 1 = v2 VALU, 2 = v2 with the per-j sums on f32 MFMA, -1 = library default")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -251,8 +254,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    from psvo_amd import dp, ops
+    from psvo_amd import _lib, dp, ops
     from psvo_amd.optim import FlatParams, TFAdam
+    _lib.check(_lib.load().psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, args.bsim_bwd_variant), "psvo_set_tuning")
     dp.init(backend=os.environ.get("PSVO_DIST_BACKEND", "nccl"), device=device)
     dist = torch.distributed if world > 1 else None
 
@@ -453,6 +457,7 @@ def main():
                        "elbo": elbo, "forward_only_particle_steps_per_s": other,
                        "launch": ("hipGraph replay" + ("" if args.graph else " (calibrated against eager issue)")) if use_graph
                                  else ("eager" + ("; " + graph_note if graph_note else "")),
+                       "bsim_bwd_variant": args.bsim_bwd_variant,
                        "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())},
                        "native_timeline_ms": timeline},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -75,6 +75,15 @@ typedef struct {
 
 int psvo_abi_version(void);
 const char* psvo_status_string(int status);
+/* Tuning switches (process-wide; for A/B measurements and tests -- results are the same to rounding under every value):
+ *   PSVO_TUNE_BSIM_BWD: which reverse backward-simulation kernel psvo_bsim_backward launches.
+ *     -1 default (measured best), 0 = lane = (chain, half, m) with per-j butterflies, 1 = "j on lanes" layout with the per-j
+ *     sums on the VALU, 2 = the same with the per-j sums on v_mfma_f32_16x16x4_f32.  It changes psvo_bsim_blocks():
+ *     set it before sizing workspaces. */
+#define PSVO_TUNE_BSIM_BWD 1
+int psvo_set_tuning(int key, int value);          /* PSVO_OK or PSVO_ERR_INVALID */
+int psvo_get_tuning(int key);
+
 /* hipGetErrorString of the most recent failed launch on the calling thread (PSVO_ERR_HIP). */
 const char* psvo_last_hip_error(void);
 
@@ -157,7 +166,7 @@ int psvo_bsim_forward(const psvo_desc* desc,
  *            dscore (B,N) = d loss / d score.
  *  outputs : rows for psvo_mlp_wgrad: xt (T,B,Dx,N,M) sub-particles, dFt (T,B,Dx,N,M) w.r.t.
  *            MLP_f(x~), dGt (T,B,Dy,N,M) w.r.t. MLP_g(x~), dmu1 (T,B,Dx,N) w.r.t. MLP_q1inv(bwX[t+1]);
- *            per-workgroup partials (nblk = psvo_bsim_blocks(B, N, M, H, Dx), to be summed over that axis):
+ *            per-workgroup partials (nblk = psvo_bsim_blocks(desc), to be summed over that axis):
  *            dFm_part (T,B,nblk,Dx,N), dlogW_part (T,B,nblk,N)  -> psvo_filter_backward,
  *            per-chain rows (to be summed over N): dbmu2_rows (T,B,Dx,N), dminit_rows (B,Dx,N),
  *            dimean_rows (B,Dx,N);
@@ -165,7 +174,7 @@ int psvo_bsim_forward(const psvo_desc* desc,
  *  sacc_part: workspace, B * nblk * psvo_bsim_acc_size(Dx, Dy) floats.
  *  The gradient w.r.t. lse is identically zero (the normalised weights' gradients sum to zero).
  * ------------------------------------------------------------------------------------------- */
-int psvo_bsim_blocks(int B, int N, int M, int H, int Dx);
+int psvo_bsim_blocks(const psvo_desc* desc);      /* nblk for this problem under the current PSVO_TUNE_BSIM_BWD setting */
 int psvo_bsim_acc_size(int Dx, int Dy);
 int psvo_bsim_backward(const psvo_desc* desc,
                        const float* Fm, const float* logW, const float* lse,
@@ -358,6 +367,10 @@ int psvo_sigma_backward(const float* raw, const float* mins, const float* dsig, 
 /* Diagnostic: runs the DPP / permlane cross-lane primitives the kernels are built on over one
  * wavefront of input (64 floats) and writes 9 x 64 results (xor 1..32, inclusive scan, sum, max). */
 int psvo_selftest_lanes(const float* in64, float* out576, void* stream);
+/* second self-test: swap-add stages over lane bits 5 / 4, 16-lane row sum, and the operand / accumulator layout of
+ * v_mfma_f32_16x16x4_f32 as bsim_bwd2 uses it.  in: 3 x 64 floats (lo, hi, extra); out: 5 x 64 floats
+ * (swap_add32, swap_add16, row_sum16, mfma D register 0, mfma D register 1). */
+int psvo_selftest_lanes2(const float* in192, float* out320, void* stream);
 
 /* Per-sequence ELBO reductions (no batch mean: the caller averages, so a batch shard can be
  * all-reduced).  filter: out[b] = sum_t lse[t,b] (SVO.compute_log_ZSMC, SVO.py:302-311);

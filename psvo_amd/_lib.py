@@ -13,6 +13,7 @@ PSVO_OK = 0
 PSVO_ERR_INVALID = -1
 PSVO_ERR_UNSUPPORTED = -2
 PSVO_ERR_HIP = -3
+PSVO_TUNE_BSIM_BWD = 1      # psvo_set_tuning key (include/psvo_hip.h)
 
 
 class PsvoHipError(RuntimeError):
@@ -45,7 +46,9 @@ SIGNATURES = {
     "psvo_mlp_wgrad": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       _P, _P, _MLP, _P, _P, ctypes.c_int, _P]),
     "psvo_bsim_forward": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 22 + [_P]),
-    "psvo_bsim_blocks": (ctypes.c_int, [ctypes.c_int] * 5),
+    "psvo_bsim_blocks": (ctypes.c_int, [_DESC]),
+    "psvo_set_tuning": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "psvo_get_tuning": (ctypes.c_int, [ctypes.c_int]),
     "psvo_bsim_acc_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "psvo_bsim_backward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 34),
     "psvo_bsimwr_blocks": (ctypes.c_int, [ctypes.c_int] * 3),
@@ -65,6 +68,7 @@ SIGNATURES = {
     "psvo_sigma_forward": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P]),
     "psvo_sigma_backward": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     "psvo_selftest_lanes": (ctypes.c_int, [_P, _P, _P]),
+    "psvo_selftest_lanes2": (ctypes.c_int, [_P, _P, _P]),
     "psvo_elbo_filter": (ctypes.c_int, [_DESC, _P, _P, _P]),
     "psvo_elbo_bsim": (ctypes.c_int, [_DESC, _P, _P, _P]),
     "psvo_elbo_bsim_mean": (ctypes.c_int, [_DESC, _P, _P, _P]),

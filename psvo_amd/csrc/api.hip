@@ -202,6 +202,31 @@ __global__ void lane_selftest_kernel(const float* __restrict__ in, float* __rest
 }
 }  // namespace psvo
 
+#include "bsim_bwd2_impl.h"
+namespace psvo {
+__global__ void lane_selftest2_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    const int l = threadIdx.x;
+    const float lo = in[l], hi = in[64 + l], ex = in[128 + l];
+    out[0 * 64 + l] = swap_add32(lo, hi);
+    out[1 * 64 + l] = swap_add16(lo, hi);
+    out[2 * 64 + l] = row_sum16(lo);
+    // D[i][j] = sum_k A[i][k] B[k][j], A operand: lane l holds A[l & 15][l >> 4]; B: B[l >> 4][l & 15];
+    // D: lane l holds rows 4 (l >> 4) + reg of column l & 15
+    f4v acc = f4v{0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lo, hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ex, hi, acc, 0, 0, 0);
+    out[3 * 64 + l] = acc[0];
+    out[4 * 64 + l] = acc[1];
+}
+}  // namespace psvo
+
+extern "C" int psvo_selftest_lanes2(const float* in192, float* out320, void* stream) {
+    if (!in192 || !out320) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
+    hipLaunchKernelGGL(psvo::lane_selftest2_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), in192, out320);
+    return psvo::launch_status();
+}
+
 extern "C" int psvo_selftest_lanes(const float* in64, float* out576, void* stream) {
     if (!in64 || !out576) return PSVO_ERR_INVALID;
     psvo::clear_hip_error();

@@ -1,16 +1,43 @@
 // C-ABI entry points of the backward-simulation reverse pass; the kernels are instantiated per Dx in
 // bsim_bwd_dx{2,3,4}.hip (one translation unit each so that hipcc compiles them in parallel).
-#include "bsim_bwd_impl.h"
+#include "bsim_bwd2_impl.h"
 
 namespace psvo {
+extern template int bb2_dispatch_dy<2>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, int, hipStream_t);
+extern template int bb2_dispatch_dy<3>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, int, hipStream_t);
+extern template int bb2_dispatch_dy<4>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, int, hipStream_t);
 extern template int bb_dispatch_dy<2>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
 extern template int bb_dispatch_dy<3>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
 extern template int bb_dispatch_dy<4>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
 }  // namespace psvo
 
-extern "C" int psvo_bsim_blocks(int B, int N, int M, int H, int Dx) {
+// Which reverse kernel psvo_bsim_backward launches (psvo_set_tuning(PSVO_TUNE_BSIM_BWD, v)):
+//   0 = v1 (lane = (chain, half, m), per-j sums by butterfly),  1 = v2 VALU (bsim_bwd2_impl.h: j on lanes, per-j sums in
+//   registers + swap-add),  2 = v2 with the per-j sums on v_mfma_f32_16x16x4_f32,  -1 = the measured default (v2 VALU where
+//   it applies).  The workspace geometry (psvo_bsim_blocks) follows the choice, so set it before sizing buffers.
+static int g_bsim_bwd_variant = -1;
+
+static int bsim_bwd_variant(int B, int T, int N, int M, int Dx, int Dy) {
+    int v = g_bsim_bwd_variant < 0 ? 1 : g_bsim_bwd_variant;
+    if (v != 0 && !psvo::bsim2_supported(B, T, N, M, Dx, Dy)) v = 0;
+    return v;
+}
+
+extern "C" int psvo_set_tuning(int key, int value) {
+    if (key == PSVO_TUNE_BSIM_BWD && value >= -1 && value <= 2) {
+        g_bsim_bwd_variant = value;
+        return PSVO_OK;
+    }
+    return PSVO_ERR_INVALID;
+}
+
+extern "C" int psvo_get_tuning(int key) { return key == PSVO_TUNE_BSIM_BWD ? g_bsim_bwd_variant : PSVO_ERR_INVALID; }
+
+extern "C" int psvo_bsim_blocks(const psvo_desc* desc) {
+    if (!desc) return PSVO_ERR_INVALID;
     int HS, NTB, cpb, nblk;
-    psvo::bsim_geometry(B, N, M, H, Dx, HS, NTB, cpb, nblk);
+    if (bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy) != 0) psvo::bsim2_geometry(desc->N, desc->M, cpb, nblk);
+    else psvo::bsim_geometry(desc->B, desc->N, desc->M, desc->H, desc->Dx, HS, NTB, cpb, nblk);
     return nblk;
 }
 
@@ -48,6 +75,15 @@ extern "C" int psvo_bsim_backward(
     a.dimean_rows = dimean_rows; a.sacc_part = sacc_part;
     BsimBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig};
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int variant = bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy);
+    if (variant != 0) {
+        switch (desc->Dx) {
+            case 2: return bb2_dispatch_dy<2>(a, o, desc->Dy, desc->H, desc->M, variant - 1, s);
+            case 3: return bb2_dispatch_dy<3>(a, o, desc->Dy, desc->H, desc->M, variant - 1, s);
+            case 4: return bb2_dispatch_dy<4>(a, o, desc->Dy, desc->H, desc->M, variant - 1, s);
+            default: return PSVO_ERR_UNSUPPORTED;
+        }
+    }
     switch (desc->Dx) {
         case 2: return bb_dispatch_dy<2>(a, o, desc->Dy, desc->H, desc->M, s);
         case 3: return bb_dispatch_dy<3>(a, o, desc->Dy, desc->H, desc->M, s);

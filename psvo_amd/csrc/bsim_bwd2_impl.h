@@ -1,0 +1,722 @@
+// Reverse-mode pass of the backward simulation, second layout ("j on lanes").  Same mathematics, inputs and outputs as
+// bsim_bwd_impl.h (read its header for the derivation); what changes is WHERE the pair work of a step lives in the wave.
+//
+// v1 (bsim_bwd_kernel) keeps lane = (chain, half, m) throughout.  In its pair loop a quad of lanes shares four
+// sub-particles and walks the forward particles j four at a time, so the per-j sums  d F'_j = sum_{chain,m} c u,
+// d W^_j = sum c  have their terms spread over the 16 quads of the wave and are brought together by a butterfly after
+// every chunk of entries: 332 of the 1705 VALU instructions of a C* step, next to 125 v_readlane + 121 s_nop that restore
+// spilled scalar registers (109 SGPRs spilled: ~30 array base pointers, index arithmetic, lane masks).
+//
+// v2 splits a step into two lane mappings that talk through a few hundred bytes of wave-private LDS:
+//   * per-(chain, m) work -- proposal recompute, MLP_f / MLP_g forward + input gradients, chain reductions, row stores --
+//     keeps lane = (chain, part, m), two lanes per (chain, m) with half of every MLP's hidden units each;
+//   * the pair phase runs with lane = (j16, g): the 16 lanes of a DPP row hold 16 consecutive forward particles of a
+//     tile, lane group g = lane >> 4 holds one ITEM = (chain, quad of four m) of the wave's 8 items per round (2 rounds).
+//     Per-j sums then accumulate IN REGISTERS over the items of both rounds (f2 accumulators, one pk_fma per term) and
+//     are reduced over the four lane groups once per step by two swap-add stages (v_permlane32_swap / v_permlane16_swap:
+//     one swap + one add per pair of values, no selects); per-(chain, m) sums  U = sum_j p u,  V = sum_j p u^2  are
+//     all-reduced over the 16 lanes of the row with four DPP row rotations.
+// Addressing: every array is read / written as base (SGPR pair) + one 32-bit byte offset per array SHAPE kept in a VGPR and
+// advanced by a constant per step, and the float loop constants live in VGPRs (common.h keep_in_vgpr): no index arithmetic
+// in the loop, no scalar-register spills.  Arrays are therefore limited to 4 GiB each (the dispatcher falls back to v1).
+//
+// MFMA variant of the per-j sums (template flag JM, measured beside the VALU form):
+//   d[F'|W^]_j = sum_k c_kj [x'_k | 1]  is  C^T [X' | 1]  with k = (item, m) -- v_mfma_f32_16x16x4_f32 takes the lane's
+//   four c values (m = 4g + r, r = register) as the B operand (k on lane groups and registers, j on the row lanes: the
+//   accumulator layout of the tile IS the operand layout) and [X' | 1]^T as the A operand; the contraction over lane
+//   groups that the swap-add stages do on the VALU is part of the instruction.
+#pragma once
+#include "bsim_bwd_impl.h"
+
+namespace psvo {
+PSVO_TIMERS_DEFINE(bsim_bwd2)
+
+// base + 32-bit byte offset: hipcc selects the saddr form (global_load_dword v, v_off, s[base:base+1])
+__device__ __forceinline__ float ldf(const float* base, unsigned off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off);
+}
+__device__ __forceinline__ int ldi(const int32_t* base, unsigned off) {
+    return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + off);
+}
+__device__ __forceinline__ void stf(float* base, unsigned off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) = v;
+}
+
+// One reduce-scatter stage over lane bit 5 (bit 4): every lane passes in the value it KEEPS a sum of on the low side
+// (`lo`: lanes 0-31 / even rows) and on the high side (`hi`); returned is, on a low-side lane, lo(own) + lo(partner) and
+// on a high-side lane hi(own) + hi(partner), partner = lane ^ 32 (lane ^ 16).  v_permlane32_swap_b32 v0, v1 exchanges lanes
+// 32-63 of v0 with lanes 0-31 of v1 (v_permlane16_swap: odd rows of v0 with even rows of v1), after which both sides add
+// v0 + v1.  (s_nop 1: two wait states between a VALU write of an operand and the swap, which hipcc does not insert
+// inside an asm statement.)
+__device__ __forceinline__ float swap_add32(float lo, float hi) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    return lo + hi;
+}
+__device__ __forceinline__ float swap_add16(float lo, float hi) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+    return lo + hi;
+}
+// sum over the 16 lanes of a DPP row, result in every lane (four rotations)
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_mov<0x128, 0xF, 0xF, true>(v, v);   // row_ror:8
+    v += dpp_mov<0x124, 0xF, 0xF, true>(v, v);   // row_ror:4
+    v += dpp_mov<0x122, 0xF, 0xF, true>(v, v);   // row_ror:2
+    v += dpp_mov<0x121, 0xF, 0xF, true>(v, v);   // row_ror:1
+    return v;
+}
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// JM = 0: per-j sums on the VALU (f2 accumulators + swap-add);  JM = 1: v_mfma_f32_16x16x4_f32
+template <int DX, int DY, int H, int M, int JM>
+__global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    using AC = BAcc<DX, DY>;
+    constexpr int PS = BTileSlot<DX>::kFloats;
+    constexpr int NA = DX + 1;            // per-j accumulators: d F' (DX) and d W^
+    constexpr int PART = 2;               // lanes per (chain, m) in the per-(chain, m) phases
+    constexpr int G = M * PART;           // lanes per chain
+    constexpr int CPW = 64 / G;           // chains per wave
+    constexpr int CM = CPW * M;           // (chain, m) slots per wave = 32
+    constexpr int NF = DX + 2;            // exchange fields per (chain, m): x' (DX), lam2, d Lambda
+    constexpr int UVS = (2 * DX + 3) & ~3;   // floats per (chain, m) of the U / V hand-back, padded to float4s
+    constexpr int JC = 8;                 // forward-particle tiles (of 16) per chunk whose per-j sums live in registers
+    static_assert(CM == 32 && (M % 4) == 0, "two lanes per (chain, m): M in {4, 8, 16, 32}");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NTB = 256, nwv = 4;
+    const int B = a.B, T = a.T, N = a.N;
+    const int NP = ((N + 16 * JC - 1) / (16 * JC)) * (16 * JC);   // tile padded (W' = -inf) to whole chunks
+    const int nch = NP / (16 * JC);
+    const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    constexpr int cpb = nwv * CPW;
+    // per-(chain, m) mapping
+    const int cl = lane / G, part = (lane / M) & 1, m = lane % M;
+    const bool h0 = (part == 0);
+    const int n_raw = blk * cpb + wave * CPW + cl;
+    const bool valid = n_raw < N;
+    const int n = valid ? n_raw : N - 1;
+    const bool srow = valid && h0;                    // the lane that stores this (chain, m)'s rows
+    const bool lead = srow && (m == 0);
+    // pair mapping
+    const int j16 = lane & 15, g = lane >> 4;
+
+    float* wf = smem;
+    float* wg = wf + MQ::kSize;
+    float* wqi = wg + MG::kSize;
+    float* tile = wqi + MQ::kSize;               // [2][NP][PS]
+    float* jacc = tile + 2 * NP * PS;            // [nwv][NA][NP] per-wave d F' / d W^ sums of the step
+    float* xch = jacc + nwv * NA * NP;           // [nwv][NF][CM]  per-(chain, m) -> pair phase
+    float* uvx = xch + nwv * NF * CM;            // [nwv][CM][UVS] pair phase -> per-(chain, m)
+    float* red = uvx + nwv * CM * UVS;           // 16
+    float* const xw = xch + wave * NF * CM;
+    float* const uw = uvx + wave * CM * UVS;
+    float* const ja = jacc + wave * NA * NP;
+
+    MQ::load(wf, a.f, tid, NTB);
+    MG::load(wg, a.g, tid, NTB);
+    MQ::load(wqi, a.q1inv, tid, NTB);
+
+    // ---- constants (VGPRs: see keep_in_vgpr) ------------------------------------------------------------------------
+    const float kappa = sqrtf(0.5f * kLog2e);
+    float isf[DX], rp[DX], isfk[DX], isg[DY];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        isf[d] = 1.f / a.sig_f[d];
+        rp[d] = isf[d] * kappa;
+        isfk[d] = isf[d] / kappa;
+    }
+    float ikap2 = 1.f / (kappa * kappa);
+#pragma unroll
+    for (int e = 0; e < DY; ++e) isg[e] = 1.f / a.sig_g[e];
+    float pc[DX], pic[DX], pi1[DX], pi2[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        pi1[d] = 1.f / a.sig_q1inv[d];
+        pi2[d] = 1.f / a.sig_bq2[d];
+        pic[d] = pi1[d] + pi2[d];
+        pc[d] = 1.f / pic[d];
+    }
+    float s_init[DX], is_init[DX], i_isig[DX], im[DX], mi[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        s_init[d] = a.sig_init[d];
+        is_init[d] = 1.f / s_init[d];
+        i_isig[d] = 1.f / a.isig[d];
+        im[d] = a.imean[b * DX + d];
+        mi[d] = a.minit[b * DX + d];
+    }
+    keep_in_vgpr(isf); keep_in_vgpr(rp); keep_in_vgpr(isfk); keep_in_vgpr(isg); keep_in_vgpr(ikap2);
+    keep_in_vgpr(pc); keep_in_vgpr(pic); keep_in_vgpr(pi1); keep_in_vgpr(pi2);
+    // (s_init, is_init, i_isig, im, mi are read in the first / last step only: scalar registers)
+    const float ninf = -__builtin_huge_valf();
+    const float aw = valid ? a.dscore[(size_t)b * N + n] : 0.f;  // d loss / d score of this chain
+
+    // ---- byte offsets of step 0, one per array shape, and their per-step strides -----------------------------------
+    const unsigned NM = (unsigned)N * M;
+    unsigned o_nm = 4u * ((unsigned)b * NM + n * M + m);                      // (T,B,N,M)     om, lam2
+    unsigned o_dnm[DX], o_knm[DY], o_dn[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        o_dnm[d] = 4u * (((unsigned)b * DX + d) * NM + n * M + m);            // (T,B,DX,N,M)  eps_b, xt, dFt
+        o_dn[d] = 4u * (((unsigned)b * DX + d) * N + n);                      // (T,B,DX,N)    bwX, mu1, dmu1, dbmu2_rows
+    }
+#pragma unroll
+    for (int k = 0; k < DY; ++k) o_knm[k] = 4u * (((unsigned)b * DY + k) * NM + n * M + m);   // (T,B,DY,N,M) dGt
+    unsigned o_n = 4u * ((unsigned)b * N + n);                                // (T,B,N)       sel
+    unsigned o_d = 4u * ((unsigned)b * DX), o_k = 4u * ((unsigned)b * DY);    // (T,B,DX) bmu2, (T,B,DY) obs   (uniform)
+    const unsigned s_nm = 4u * B * NM, s_dnm = s_nm * DX, s_knm = s_nm * DY, s_dn = 4u * B * DX * N, s_n = 4u * B * N,
+                   s_d = 4u * B * DX, s_k = 4u * B * DY;
+
+    // ---- forward-tile staging (image identical to v1 / the forward kernel) ---------------------------------------------
+    float st[DX + 1], st_l = 0.f;
+    int st_t = 0;
+    auto put_slot = [&](float* buf, int j, const float (&raw)[DX + 1], float l) {
+        float F[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) F[d] = raw[d] * rp[d];
+        const float W = j < N ? (raw[DX] - l) * kLog2e : ninf;
+        if constexpr (DX <= 3) {
+            float4 v;
+            v.x = F[0];
+            v.y = DX > 1 ? F[DX > 1 ? 1 : 0] : 0.f;
+            v.z = DX > 2 ? F[DX > 2 ? 2 : 0] : 0.f;
+            v.w = W;
+            *reinterpret_cast<float4*>(buf + j * PS) = v;
+        } else {
+            *reinterpret_cast<float4*>(buf + j * PS) = make_float4(F[0], F[1], F[2], F[3]);
+            *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(W, 0.f, 0.f, 0.f);
+        }
+    };
+    auto get_slot = [&](int tt, int j, float (&raw)[DX + 1]) {
+        const unsigned tb = (unsigned)tt * B + b;
+        const unsigned jc = j < N ? j : N - 1;
+        const float* Fm = PSVO_ARG(BsimBwdArgs, Fm);
+#pragma unroll
+        for (int d = 0; d < DX; ++d) raw[d] = ldf(Fm, 4u * ((tb * DX + d) * N + jc));
+        raw[DX] = ldf(PSVO_ARG(BsimBwdArgs, logW), 4u * (tb * N + jc));
+    };
+    auto stage_load = [&](int tt) {
+        st_t = tt;
+        st_l = ldf(PSVO_ARG(BsimBwdArgs, lse), 4u * ((unsigned)tt * B + b));
+        if (tid < NP) get_slot(tt, tid, st);
+    };
+    auto stage_store = [&](float* buf) {
+        if (tid < NP) put_slot(buf, tid, st, st_l);
+        for (int j = tid + NTB; j < NP; j += NTB) {
+            float raw[DX + 1];
+            get_slot(st_t, j, raw);
+            put_slot(buf, j, raw, st_l);
+        }
+    };
+    if (T >= 2) {   // step t reads forward tile t-1; the first tile needed is tile(0) at t = 1
+        stage_load(0);
+        stage_store(tile);
+    }
+    __syncthreads();
+
+    float acc[AC::kN];
+#pragma unroll
+    for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
+    float dX[DX];  // d loss / d bwX_t of this chain (all lanes of the chain hold the same value)
+#pragma unroll
+    for (int d = 0; d < DX; ++d) dX[d] = 0.f;
+
+    // per-step inputs, requested one step ahead of their use (issue only)
+    struct StepIn {
+        float eps[DX], bm[DX], xp[DX], mu1[DX], y[DY], om, lam2;
+        int sel;
+    };
+    auto load_step = [&](bool lst, bool fst, StepIn& s) {    // (the offsets already point at the step to load)
+        s.sel = ldi(PSVO_ARG(BsimBwdArgs, sel), o_n);
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            s.eps[d] = ldf(PSVO_ARG(BsimBwdArgs, eps_b), o_dnm[d]);
+            s.bm[d] = ldf(PSVO_ARG(BsimBwdArgs, bmu2), o_d + 4u * d);
+            s.xp[d] = lst ? 0.f : ldf(PSVO_ARG(BsimBwdArgs, bwX), o_dn[d] + s_dn);
+            s.mu1[d] = lst ? 0.f : ldf(PSVO_ARG(BsimBwdArgs, mu1_all), o_dn[d]);
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) s.y[k] = ldf(PSVO_ARG(BsimBwdArgs, obs), o_k + 4u * k);
+        s.om = ldf(PSVO_ARG(BsimBwdArgs, om_all), o_nm);
+        s.lam2 = fst ? 0.f : ldf(PSVO_ARG(BsimBwdArgs, lam2_all), o_nm);
+    };
+    auto advance = [&]() {
+        o_nm += s_nm; o_n += s_n; o_d += s_d; o_k += s_k;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) { o_dnm[d] += s_dnm; o_dn[d] += s_dn; }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) o_knm[k] += s_knm;
+    };
+    StepIn cur_in, nxt_in;
+    load_step(T == 1, true, cur_in);
+
+    SEC_INIT(bsim_bwd2)
+    for (int t = 0; t < T; ++t) {
+        SEC(0);
+        const bool first = (t == 0), last = (t == T - 1);
+        const float* cur = tile + ((t + 1) & 1) * NP * PS;  // tile(t-1), valid for t >= 1
+        float* nxt = tile + (t & 1) * NP * PS;              // tile(t) for step t+1
+        if (t + 1 < T && t >= 1) stage_load(t);
+        // the offsets are advanced to step t+1 for the prefetch; this step's stores subtract the stride again
+        advance();
+        if (t + 1 < T) load_step(t + 2 == T, false, nxt_in);
+        SEC(1);   // issue of the prefetch loads
+
+        // ---- recompute the proposal ---------------------------------------------------------------------
+        float xp[DX], eps[DX], bm[DX], mu1[DX], mu[DX], x[DX], y[DY];
+        const int sel = cur_in.sel;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            eps[d] = cur_in.eps[d];
+            bm[d] = cur_in.bm[d];
+            xp[d] = cur_in.xp[d];
+            mu1[d] = cur_in.mu1[d];
+            if (!last) {
+                mu[d] = pc[d] * fmaf(pi1[d], mu1[d], pi2[d] * bm[d]);
+                x[d] = fmaf(pc[d], eps[d], mu[d]);
+            } else {
+                mu[d] = mi[d];
+                x[d] = fmaf(s_init[d], eps[d], mu[d]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) y[k] = cur_in.y[k];
+        const float pi_m = valid ? exp2_fast(cur_in.om * kLog2e) : 0.f;
+        const float issel = (m == sel) ? 1.f : 0.f;
+        const float dphi = aw * pi_m;                 // = d g_m = d iota_m
+        const float dlam = -aw * (issel - pi_m);
+
+        float dxt[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) dxt[d] = h0 ? issel * dX[d] : 0.f;  // dxt: this lane's PARTIAL of d x~_m
+
+        SEC(2);   // proposal recompute, coefficients
+        if (!first) {
+            // ---- hand (x', lam2, d Lambda) of the wave's 32 (chain, m) to the pair mapping ---------------------------
+            if (h0) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) xw[d * CM + cl * M + m] = x[d] * rp[d];
+                xw[DX * CM + cl * M + m] = cur_in.lam2;
+                xw[(DX + 1) * CM + cl * M + m] = dlam;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---- pair phase: lane = (j16, g); item of round r: it = 4 r + g = (chain, quad) ---------------------------
+            f2 Ua[2][DX], Ub[2][DX], Va[2][DX], Vb[2][DX];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int d = 0; d < DX; ++d) Ua[r][d] = Ub[r][d] = Va[r][d] = Vb[r][d] = f2{0.f, 0.f};
+
+            for (int c = 0; c < nch; ++c) {
+                float A2[JC][NA];       // JM = 0: per-j sums over the lane's items
+                f4v D4[JC];             // JM = 1: MFMA accumulators (rows = [d F'_0.., d W^], columns = the 16 j of a tile)
+#pragma unroll
+                for (int jt = 0; jt < JC; ++jt) {
+#pragma unroll
+                    for (int e = 0; e < NA; ++e) A2[jt][e] = 0.f;
+                    D4[jt] = f4v{0.f, 0.f, 0.f, 0.f};
+                }
+                const float* cbase = cur + (c * 16 * JC + j16) * PS;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int it4 = 4 * (4 * r + g);          // first (chain, m) slot of the item
+                    f2 xa[DX], xb[DX];
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) {
+                        const float4 v = *reinterpret_cast<const float4*>(xw + d * CM + it4);
+                        xa[d] = f2{v.x, v.y};
+                        xb[d] = f2{v.z, v.w};
+                    }
+                    const float4 lq = *reinterpret_cast<const float4*>(xw + DX * CM + it4);
+                    const float4 dl = *reinterpret_cast<const float4*>(xw + (DX + 1) * CM + it4);
+                    const f2 lqa = f2{lq.x, lq.y}, lqb = f2{lq.z, lq.w};
+                    const f2 dla = f2{dl.x, dl.y}, dlb = f2{dl.z, dl.w};
+                    // JM = 1: A operand of the per-j MFMA, [X' | 1]^T: lane (i = j16, kk = g) holds row i of column
+                    // k = 4 g + rr for MFMA rr: i < DX: x'_i of sub-particle rr, i == DX: 1, else 0
+                    float xop[4];
+                    if constexpr (JM == 1) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            float v = (j16 == DX) ? 1.f : 0.f;
+#pragma unroll
+                            for (int d = 0; d < DX; ++d) {
+                                const float xv = (rr == 0) ? xa[d].x : (rr == 1) ? xa[d].y : (rr == 2) ? xb[d].x : xb[d].y;
+                                v = (j16 == d) ? xv : v;
+                            }
+                            xop[rr] = v;
+                        }
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < JC; ++jt) {
+                        float F[DX], W;
+                        read_slot<DX>(cbase + jt * 16 * PS, F, W);
+                        f2 ua[DX], ub[DX], la = f2{W, W}, lb = la;
+#pragma unroll
+                        for (int d = 0; d < DX; ++d) {
+                            const f2 Fd = f2{F[d], F[d]};
+                            ua[d] = xa[d] - Fd;
+                            ub[d] = xb[d] - Fd;
+                            la = pk_fma(-ua[d], ua[d], la);
+                            lb = pk_fma(-ub[d], ub[d], lb);
+                        }
+                        la -= lqa;
+                        lb -= lqb;
+                        const f2 pa = f2{exp2_fast(la.x), exp2_fast(la.y)}, pb = f2{exp2_fast(lb.x), exp2_fast(lb.y)};
+                        const f2 ca = dla * pa, cb = dlb * pb;
+#pragma unroll
+                        for (int d = 0; d < DX; ++d) {
+                            const f2 pua = pa * ua[d], pub = pb * ub[d];
+                            Ua[r][d] += pua;
+                            Ub[r][d] += pub;
+                            Va[r][d] = pk_fma(pua, ua[d], Va[r][d]);
+                            Vb[r][d] = pk_fma(pub, ub[d], Vb[r][d]);
+                        }
+                        if constexpr (JM == 0) {
+                            const f2 cs = ca + cb;
+                            A2[jt][DX] += cs.x + cs.y;
+#pragma unroll
+                            for (int d = 0; d < DX; ++d) {
+                                const f2 ad = pk_fma(cb, ub[d], ca * ua[d]);
+                                A2[jt][d] += ad.x + ad.y;
+                            }
+                        } else {
+                            // d F'_j wants sum c (x' - F'_j) = (sum c x') - F'_j (sum c): the MFMA forms sum c [x' | 1];
+                            // the F'_j term is applied at the flush
+                            D4[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xop[0], ca.x, D4[jt], 0, 0, 0);
+                            D4[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xop[1], ca.y, D4[jt], 0, 0, 0);
+                            D4[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xop[2], cb.x, D4[jt], 0, 0, 0);
+                            D4[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xop[3], cb.y, D4[jt], 0, 0, 0);
+                        }
+                    }
+                }
+                // ---- flush the chunk's per-j sums: reduce over the four lane groups, one owner lane per (j, e) -----------
+                if constexpr (JM == 0) {
+                    float v[JC][NA];
+#pragma unroll
+                    for (int jt = 0; jt < JC; ++jt)
+#pragma unroll
+                        for (int e = 0; e < NA; ++e) v[jt][e] = A2[jt][e];
+#pragma unroll
+                    for (int jt = 0; jt < JC / 2; ++jt)
+#pragma unroll
+                        for (int e = 0; e < NA; ++e) v[jt][e] = swap_add32(v[jt][e], v[jt + JC / 2][e]);
+#pragma unroll
+                    for (int jt = 0; jt < JC / 4; ++jt)
+#pragma unroll
+                        for (int e = 0; e < NA; ++e) v[jt][e] = swap_add16(v[jt][e], v[jt + JC / 4][e]);
+                    // lane (g, j16) now owns tiles (JC/2)(g >> 1) + (JC/4)(g & 1) + {0 .. JC/4 - 1}
+                    const int jt0 = (JC / 2) * (g >> 1) + (JC / 4) * (g & 1);
+#pragma unroll
+                    for (int jt = 0; jt < JC / 4; ++jt)
+#pragma unroll
+                        for (int e = 0; e < NA; ++e) ja[e * NP + (c * JC + jt0 + jt) * 16 + j16] = v[jt][e];
+                } else {
+                    // accumulator layout: lane (column j16, rows 4 g + reg); rows 0 .. DX are [sum c x'_d .., sum c]
+                    if (g == 0 || DX > 3) {
+#pragma unroll
+                        for (int jt = 0; jt < JC; ++jt) {
+                            float F[DX], W;
+                            read_slot<DX>(cbase + jt * 16 * PS, F, W);
+                            (void)W;
+                            const int j = (c * JC + jt) * 16 + j16;
+                            if constexpr (DX <= 3) {
+                                const float sc = D4[jt][DX];
+#pragma unroll
+                                for (int d = 0; d < DX; ++d) ja[d * NP + j] = D4[jt][d] - F[d] * sc;
+                                ja[DX * NP + j] = sc;
+                            } else {
+                                // DX = 4: sum c is row 4 = register 0 of lane group 1
+                                const float sc = __shfl(D4[jt][0], 16 + j16);
+                                if (g == 0) {
+#pragma unroll
+                                    for (int d = 0; d < DX; ++d) ja[d * NP + j] = D4[jt][d] - F[d] * sc;
+                                    ja[DX * NP + j] = sc;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- U, V of every item: sum over the 16 forward particles of the row, hand back per (chain, m) -------------
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                float o[4][UVS];
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    o[0][d] = row_sum16(Ua[r][d].x); o[1][d] = row_sum16(Ua[r][d].y);
+                    o[2][d] = row_sum16(Ub[r][d].x); o[3][d] = row_sum16(Ub[r][d].y);
+                    o[0][DX + d] = row_sum16(Va[r][d].x); o[1][DX + d] = row_sum16(Va[r][d].y);
+                    o[2][DX + d] = row_sum16(Vb[r][d].x); o[3][DX + d] = row_sum16(Vb[r][d].y);
+                }
+                if (j16 == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int e = 2 * DX; e < UVS; ++e) o[i][e] = 0.f;
+                        float* dst = uw + (4 * (4 * r + g) + i) * UVS;
+#pragma unroll
+                        for (int e = 0; e < UVS; e += 4)
+                            *reinterpret_cast<float4*>(dst + e) = make_float4(o[i][e], o[i][e + 1], o[i][e + 2], o[i][e + 3]);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            SEC(3);   // pair phase
+            if (h0) {
+                float uv[UVS];
+#pragma unroll
+                for (int e = 0; e < UVS; e += 4) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(uw + (cl * M + m) * UVS + e);
+                    uv[e] = q4.x; uv[e + 1] = q4.y; uv[e + 2] = q4.z; uv[e + 3] = q4.w;
+                }
+                // (x~-F)/sigma^2 = u / (sigma kappa);  z^2 = u^2 / kappa^2
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    dxt[d] -= dlam * uv[d] * isfk[d];
+                    acc[AC::kSf + d] += dlam * (uv[DX + d] * ikap2 - 1.f) * isf[d];
+                }
+            }
+        } else {
+            // t = 0: iota_m = LN(x~; imean, isig)   (reference PSVO.py:169-175)
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                const float z = (x[d] - im[d]) * i_isig[d];
+                const float tz = dphi * z * i_isig[d];
+                if (h0) {
+                    dxt[d] -= tz;
+                    acc[AC::kSiota + d] += dphi * (z * z - 1.f) * i_isig[d];
+                }
+            }
+        }
+
+        SEC(4);   // hand-back
+        // ---- f(x_{t+1} | x~), g(y_t | x~) ------------------------------------------------------------------------
+        float dxp_part[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) dxp_part[d] = 0.f;
+        {
+            float dFo[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) dFo[d] = 0.f;
+            if (!last) {
+                float fmx[DX];
+                MQ::template eval_part<PART>(wf, part, x, fmx);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) fmx[d] += xor_lane<M>(fmx[d]);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    const float z = (xp[d] - fmx[d]) * isf[d];
+                    dFo[d] = dphi * z * isf[d];
+                    if (h0) {
+                        dxp_part[d] = -dFo[d];
+                        acc[AC::kSf + d] += dphi * (z * z - 1.f) * isf[d];
+                    }
+                }
+                MQ::template bwd_input_part<PART>(wf, part, x, dFo, dxt);
+            }
+            if (srow) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    stf(PSVO_ARG(BsimBwdArgs, dFt), o_dnm[d] - s_dnm, dFo[d]);
+                    stf(PSVO_ARG(BsimBwdArgs, xt), o_dnm[d] - s_dnm, x[d]);
+                }
+            }
+            float gm[DY], dGo[DY];
+            MG::template eval_part<PART>(wg, part, x, gm);
+#pragma unroll
+            for (int k = 0; k < DY; ++k) gm[k] += xor_lane<M>(gm[k]);
+#pragma unroll
+            for (int k = 0; k < DY; ++k) {
+                float dmean = 1.f;
+                if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
+                const float z = (y[k] - gm[k]) * isg[k];
+                dGo[k] = dphi * z * isg[k] * dmean;
+                if (h0) acc[AC::kSg + k] += dphi * (z * z - 1.f) * isg[k];
+                if (srow) stf(PSVO_ARG(BsimBwdArgs, dGt), o_knm[k] - s_knm, dGo[k]);
+            }
+            MG::template bwd_input_part<PART>(wg, part, x, dGo, dxt);
+        }
+
+        SEC(5);   // MLP_f / MLP_g forward + input gradients, row stores
+        // ---- reduce over the chain's M sub-particles and the two parts ---------------------------------------------
+        float dmu[DX], sce[DX], dxp[DX], dim[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            const float v3 = (first && h0) ? dphi * (x[d] - im[d]) * i_isig[d] * i_isig[d] : 0.f;
+            dmu[d] = group_sum<G>(dxt[d]);
+            sce[d] = group_sum<G>(dxt[d] * eps[d]);
+            dxp[d] = group_sum<G>(dxp_part[d]);
+            dim[d] = first ? group_sum<G>(v3) : 0.f;
+        }
+        float outv[DX];  // per-chain value that is summed over the chains afterwards: d bmu2 / d minit
+        if (!last) {
+            float dmu1[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                dmu1[d] = dmu[d] * pc[d] * pi1[d];
+                outv[d] = dmu[d] * pc[d] * pi2[d];
+                if (lead) {
+                    stf(PSVO_ARG(BsimBwdArgs, dmu1), o_dn[d] - s_dn, dmu1[d]);
+                    acc[AC::kSc + d] += sce[d] + aw * pic[d];   // -sum_m dq_m / c = a / c
+                    acc[AC::kSmm1 + d] += dmu[d] * mu1[d];
+                    acc[AC::kSmb + d] += dmu[d] * bm[d];
+                    acc[AC::kSmm + d] += dmu[d] * mu[d];
+                }
+            }
+            // MLP_q1inv's input is the same in all G lanes of the chain: spread its hidden units over kQS of them
+            {
+                constexpr int kQS = (H / 4 < G) ? H / 4 : G;
+                float dq[DX];
+#pragma unroll
+                for (int d = 0; d < DX; ++d) dq[d] = 0.f;
+                MQ::template bwd_input_part<kQS>(wqi, (lane % G) & (kQS - 1), xp, dmu1, dq);
+#pragma unroll
+                for (int d = 0; d < DX; ++d) dxp[d] += group_sum<kQS>(dq[d]);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                outv[d] = dmu[d];
+                if (lead) {
+                    stf(PSVO_ARG(BsimBwdArgs, dmu1), o_dn[d] - s_dn, 0.f);
+                    acc[AC::kSinit + d] += sce[d] + aw * is_init[d];
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DX; ++d) dX[d] = dxp[d];
+        if (lead) {
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                stf(PSVO_ARG(BsimBwdArgs, dbmu2_rows), o_dn[d] - s_dn, last ? 0.f : outv[d]);
+                if (last) PSVO_ARG(BsimBwdArgs, dminit_rows)[((size_t)b * DX + d) * N + n] = outv[d];
+                if (first) PSVO_ARG(BsimBwdArgs, dimean_rows)[((size_t)b * DX + d) * N + n] = dim[d];
+            }
+        }
+        SEC(6);   // chain reductions, MLP_q1inv input gradient
+        __syncthreads();
+        // ---- this workgroup's partial of d Fm[t-1] / d logW[t-1]: fold the four waves (fixed order) ------------------------
+        const size_t tb = (size_t)t * B + b;
+        if (!first) {
+            const size_t tbm = tb - B;
+            float* const pF = PSVO_ARG(BsimBwdArgs, dFm_part) + (tbm * nblk + blk) * DX * N;
+            float* const pW = PSVO_ARG(BsimBwdArgs, dlogW_part) + (tbm * nblk + blk) * N;
+            for (int j = tid; j < N; j += NTB) {
+#pragma unroll
+                for (int d = 0; d < NA; ++d) {
+                    const float* col = jacc + d * NP + j;
+                    const float a0 = col[0], a1 = col[NA * NP], a2 = col[2 * NA * NP], a3 = col[3 * NA * NP];
+                    const float s = (a0 + a1) + (a2 + a3);
+                    if (d < DX) pF[d * N + j] = s * isfk[d < DX ? d : 0];
+                    else pW[j] = s;
+                }
+            }
+        }
+        if (last) {
+            float* const pF = PSVO_ARG(BsimBwdArgs, dFm_part) + (tb * nblk + blk) * DX * N;
+            float* const pW = PSVO_ARG(BsimBwdArgs, dlogW_part) + (tb * nblk + blk) * N;
+            for (int j = tid; j < N; j += NTB) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) pF[d * N + j] = 0.f;
+                pW[j] = 0.f;
+            }
+        }
+        SEC(7);   // barrier, workgroup sums, d Fm / d logW flush
+        if (t + 1 < T && t >= 1) stage_store(nxt);
+        cur_in = nxt_in;
+        __syncthreads();
+        SEC(8);   // tile store + barrier
+    }
+
+    // ---- scalar accumulators: reduce over the workgroup ---------------------------------------------------------------
+    for (int i = 0; i < AC::kN; ++i) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < AC::kN; ++k) v = (k == i) ? acc[k] : v;
+        v = wave_sum(v);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < nwv; ++w) s += red[w];
+            a.sacc_part[((size_t)b * nblk + blk) * AC::kN + i] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// v2 geometry: 256-thread workgroups, two lanes per (chain, m)
+static inline void bsim2_geometry(int N, int M, int& cpb, int& nblk) {
+    cpb = 4 * (64 / (2 * M));
+    nblk = (N + cpb - 1) / cpb;
+}
+
+// v2 covers M in {4, 8, 16, 32} and arrays below 4 GiB (32-bit byte offsets)
+static inline bool bsim2_supported(int B, int T, int N, int M, int Dx, int Dy) {
+    if (!(M == 4 || M == 8 || M == 16 || M == 32)) return false;
+    const long long big = (long long)T * B * (Dx > Dy ? Dx : Dy) * N * M * 4;
+    return big < (1ll << 32);
+}
+
+template <int DX, int DY, int H, int M>
+static int launch_bsim_bwd2(const BsimBwdArgs& a, const BsimBwdOut& o, int jm, hipStream_t stream) {
+    using MQ = MlpLds<DX, H, DX>;
+    using MG = MlpLds<DX, H, DY>;
+    constexpr int PS = BTileSlot<DX>::kFloats;
+    constexpr int UVS = (2 * DX + 3) & ~3;
+    int cpb, nblk;
+    bsim2_geometry(a.N, M, cpb, nblk);
+    const int NP = ((a.N + 127) / 128) * 128;
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + 4 * (size_t)(DX + 1) * NP +
+                                        4 * (DX + 2) * 32 + 4 * 32 * UVS + 16);
+    if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
+    clear_hip_error();
+    if (jm == 1)
+        hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 1>), dim3(nblk, a.B), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 0>), dim3(nblk, a.B), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((bsim_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc_part, a.B * nblk,
+                       a.sig_q1inv, a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
+    return launch_status();
+}
+
+template <int DX, int DY, int H>
+static int bb2_dispatch_m(const BsimBwdArgs& a, const BsimBwdOut& o, int M, int jm, hipStream_t s) {
+    switch (M) {
+        case 4: return launch_bsim_bwd2<DX, DY, H, 4>(a, o, jm, s);
+        case 8: return launch_bsim_bwd2<DX, DY, H, 8>(a, o, jm, s);
+        case 16: return launch_bsim_bwd2<DX, DY, H, 16>(a, o, jm, s);
+        case 32: return launch_bsim_bwd2<DX, DY, H, 32>(a, o, jm, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+template <int DX, int DY>
+static int bb2_dispatch_h(const BsimBwdArgs& a, const BsimBwdOut& o, int H, int M, int jm, hipStream_t s) {
+    switch (H) {
+        case 16: return bb2_dispatch_m<DX, DY, 16>(a, o, M, jm, s);
+        case 32: return bb2_dispatch_m<DX, DY, 32>(a, o, M, jm, s);
+        case 64: return bb2_dispatch_m<DX, DY, 64>(a, o, M, jm, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+// external linkage: explicitly instantiated once per DX in bsim_bwd2_dx{2,3,4}.hip
+template <int DX>
+int bb2_dispatch_dy(const BsimBwdArgs& a, const BsimBwdOut& o, int Dy, int H, int M, int jm, hipStream_t s) {
+    switch (Dy) {
+        case 1: return bb2_dispatch_h<DX, 1>(a, o, H, M, jm, s);
+        case 2: return bb2_dispatch_h<DX, 2>(a, o, H, M, jm, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace psvo

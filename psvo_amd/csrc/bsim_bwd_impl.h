@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         rp[d] = isf[d] * kappa;
         isfk[d] = isf[d] / kappa;      // (divisions by loop constants are hoisted: an IEEE division is ~10 VALU instructions)
     }
-    const float ikap2 = 1.f / (kappa * kappa);
+    float ikap2 = 1.f / (kappa * kappa);
+    keep_in_vgpr(ikap2);
 #pragma unroll
     for (int e = 0; e < DY; ++e) isg[e] = 1.f / a.sig_g[e];
     float pc[DX], pic[DX], pi1[DX], pi2[DX];
@@ -184,6 +185,9 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
     }
     const float ninf = -__builtin_huge_valf();
     const float aw = valid ? a.dscore[(size_t)b * N + n] : 0.f;  // d loss / d score of this chain
+    keep_in_vgpr(sf); keep_in_vgpr(isf); keep_in_vgpr(rp); keep_in_vgpr(isfk); keep_in_vgpr(isg);
+    keep_in_vgpr(pc); keep_in_vgpr(pic); keep_in_vgpr(pi1); keep_in_vgpr(pi2);
+    keep_in_vgpr(s_init); keep_in_vgpr(is_init); keep_in_vgpr(i_isig); keep_in_vgpr(im); keep_in_vgpr(mi);
 
     // ---- forward-tile staging (identical image to the forward kernel) -----------------------------------
     // raw values are loaded at the top of a step and only scaled / written to LDS at its end, so that nothing

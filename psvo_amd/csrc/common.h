@@ -1,5 +1,6 @@
 // Device-side helpers shared by the filter and backward-simulation kernels (gfx950 only).
 #pragma once
+#include <cstddef>
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -74,6 +75,35 @@ __device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_lo
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 pk_max(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
+
+// Wave-uniform loop constants (inverse scales, proposal coefficients ...) would be kept in SGPRs by hipcc; the persistent
+// kernels hold 20-30 array base pointers (two SGPRs each) on top of them, more than the 102 SGPRs a wave has, and every
+// SGPR that does not fit is spilled to a VGPR lane and read back with v_readlane_b32 + s_nop INSIDE the time loop
+// (bsim_bwd at C*: 109 spilled SGPRs, 125 v_readlane + 121 s_nop per step).  An empty asm with a "+v" constraint makes
+// the value opaque in a VGPR: one v_mov before the loop, no scalar register, and VALU instructions that read two such
+// constants need no extra v_mov for the constant-bus limit either.
+__device__ __forceinline__ void keep_in_vgpr(float& x) { asm volatile("" : "+v"(x)); }
+template <int K>
+__device__ __forceinline__ void keep_in_vgpr(float (&x)[K]) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) asm volatile("" : "+v"(x[i]));
+}
+
+// Re-read a POINTER kernel argument from the kernarg segment at its point of use.  The persistent kernels take 20-30
+// array pointers; hipcc loads them all into SGPRs in the prologue and keeps them live across the time loop (two SGPRs
+// each), which is what overflows the 102 SGPRs of a wave.  Routed through this helper an argument costs one s_load_dwordx2
+// (scalar cache, off the VALU) where it is used and no register in between: the opaque offset keeps hipcc from hoisting
+// the load back out of the loop.  `byte_off` = offsetof(ArgsStruct, field); the struct is the kernel's only parameter.
+template <class T>
+__device__ __forceinline__ T* arg_ptr(unsigned byte_off) {
+    asm volatile("" : "+s"(byte_off));
+    typedef const char __attribute__((address_space(4))) * kptr;
+    const kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef T* const __attribute__((address_space(4))) * pptr;
+    return *(pptr)(kp + byte_off);
+}
+#define PSVO_ARG(args_type, field) \
+    ::psvo::arg_ptr<std::remove_pointer_t<decltype(args_type::field)>>((unsigned)offsetof(args_type, field))
 
 // ---------------------------------------------------------------------------------------------
 // One-hidden-layer MLP with weights staged in LDS, read as wave-uniform float4 broadcasts.

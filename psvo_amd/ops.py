@@ -414,7 +414,7 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
         if bs.get(k) is None:
             raise ValueError("bsim_backward needs bsim_forward(save=True) outputs (missing %s)" % k)
         _chk(bs[k], shp, k)
-    nblk = lib.psvo_bsim_blocks(B, N, M, H, Dx)
+    nblk = lib.psvo_bsim_blocks(ctypes.byref(desc))
     z = lambda *s: _empty(*s, device=dev)
     out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
            "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N),

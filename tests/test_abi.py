@@ -34,7 +34,17 @@ def test_version_and_status_strings(built_lib):
     assert lib.psvo_status_string(0) == b"ok"
     assert b"unsupported" in lib.psvo_status_string(_lib.PSVO_ERR_UNSUPPORTED)
     assert lib.psvo_filter_acc_size(2, 1) == 21 and lib.psvo_bsim_acc_size(3, 2) == 23
-    assert lib.psvo_bsim_blocks(32, 128, 16, 32, 2) == 16 and lib.psvo_bsim_blocks(32, 128, 16, 32, 3) == 8 and lib.psvo_bsim_blocks(2, 8, 4, 16, 2) == 1
+    import ctypes
+    from psvo_amd import ops
+    blocks = lambda B, T, N, M, H, Dx, Dy=1: lib.psvo_bsim_blocks(ctypes.byref(ops.make_desc(B, T, N, M, Dx, Dy, H)))
+    assert lib.psvo_get_tuning(_lib.PSVO_TUNE_BSIM_BWD) == -1
+    assert lib.psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, 0) == 0           # v1 geometry: lane = (chain, half, m)
+    assert blocks(32, 200, 128, 16, 32, 2) == 16 and blocks(32, 200, 128, 16, 32, 3) == 8 and blocks(2, 6, 8, 4, 16, 2) == 1
+    assert lib.psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, 1) == 0           # v2: 8 chains per 256-thread workgroup at M = 16
+    assert blocks(32, 200, 128, 16, 32, 2) == 16 and blocks(32, 200, 128, 16, 32, 3) == 16 and blocks(2, 6, 8, 4, 16, 2) == 1
+    assert blocks(64, 1000, 512, 16, 32, 4) == 32                         # (4 GiB per array: v1 geometry)
+    assert lib.psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, 7) == _lib.PSVO_ERR_INVALID
+    assert lib.psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, -1) == 0
     assert lib.psvo_mlp_wgrad_blocks(10) == 1 and lib.psvo_mlp_wgrad_blocks(10 ** 9) == 1024
 
 

@@ -302,6 +302,66 @@ def test_cross_lane_primitives(built_lib):
     assert torch.equal(out[8], x.max().expand(64))
 
 
+def test_cross_lane_primitives2(built_lib):
+    """swap-add stages (v_permlane32_swap / v_permlane16_swap), the 16-lane row sum and the operand / accumulator layout of
+    v_mfma_f32_16x16x4_f32 that csrc/bsim_bwd2_impl.h relies on, against their definitions"""
+    import ctypes
+    from psvo_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 64, generator=g)
+    xin, out = x.cuda().contiguous(), torch.empty(5 * 64, device="cuda")
+    st = lib.psvo_selftest_lanes2(ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(st, "psvo_selftest_lanes2")
+    out = out.cpu().view(5, 64)
+    lo, hi, ex = x[0], x[1], x[2]
+    lanes = torch.arange(64)
+    for row, mask in ((0, 32), (1, 16)):
+        low_side = (lanes & mask) == 0
+        want = torch.where(low_side, lo + lo[lanes ^ mask], hi + hi[lanes ^ mask])
+        assert torch.equal(out[row], want), "swap_add%d" % mask
+    assert torch.allclose(out[2], lo.view(4, 16).sum(1, keepdim=True).expand(4, 16).reshape(64), atol=1e-5)
+    # D = A1 B + A2 B with A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[i][j] in lane 16 (i // 4) + j, register i % 4
+    A1, A2, Bm = lo.view(4, 16).t().double(), ex.view(4, 16).t().double(), hi.view(4, 16).double()
+    D = (A1 + A2) @ Bm                                     # (16 i, 16 j)
+    for reg in (0, 1):
+        want = torch.stack([D[4 * (l // 16) + reg, l % 16] for l in range(64)]).float()
+        assert torch.allclose(out[3 + reg], want, atol=1e-5), "mfma 16x16x4 register %d" % reg
+
+
+BSIM_BWD_VARIANT_CASES = [c for c in CASES if c[0] == "PSVO"] + [("PSVO", 2, 9, 128, 16, 2, 1, 32, True, True),
+                                                                ("PSVO", 1, 6, 200, 8, 3, 1, 32, True, True),
+                                                                ("PSVO", 1, 5, 300, 32, 4, 2, 16, True, True)]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("case", BSIM_BWD_VARIANT_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_bsim_backward_variants(built_lib, case, variant):
+    """psvo_bsim_backward under every PSVO_TUNE_BSIM_BWD setting -- v1 (lane = (chain, half, m), per-j butterflies), v2
+    ("j on lanes", per-j sums in registers + swap-add) and v2 with the per-j sums on v_mfma_f32_16x16x4_f32 -- every
+    gradient against the fp64 oracle's autograd (teacher-forced indices), same tolerance for all three"""
+    from psvo_amd import _lib
+    lib = _lib.load()
+    obj = case[0]
+    FLAGS, model, smc, obs, noise = _setup(*case, seed=17)
+    _, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
+    teacher = {"idx_f": ref0["idx_f"], "idx_b": ref0["idx_b"]}
+    z_ref, P = _oracle_grads(model, FLAGS, obj, obs, noise, teacher)
+    nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
+    nz.pop("u_f", None); nz.pop("u_b", None)
+    assert lib.psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, variant) == 0
+    try:
+        model.zero_grad()
+        z, _ = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
+        z.backward()
+        torch.cuda.synchronize()
+    finally:
+        lib.psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, -1)
+    assert abs(float(z.detach()) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+    _check_grads(model, P)
+
+
 @pytest.mark.parametrize("case,extra", ENCODER_CASES + EMISSION_CASES, ids=lambda c: "-".join(map(str, c)) if isinstance(c, tuple) else
                          ",".join("%s=%s" % kv for kv in c.items()))
 def test_encoder_variants(built_lib, case, extra):
