@@ -256,7 +256,8 @@ def main():
 
     from psvo_amd import _lib, dp, ops
     from psvo_amd.optim import FlatParams, TFAdam
-    _lib.check(_lib.load().psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, args.bsim_bwd_variant), "psvo_set_tuning")
+    if args.bsim_bwd_variant >= 0:
+        _lib.check(_lib.load().psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, args.bsim_bwd_variant), "psvo_set_tuning")
     dp.init(backend=os.environ.get("PSVO_DIST_BACKEND", "nccl"), device=device)
     dist = torch.distributed if world > 1 else None
 

@@ -94,6 +94,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        v = os.environ.get("PSVO_BSIM_BWD_VARIANT")      # A/B measurements (tools/, bench.py --bsim-bwd-variant)
+        if v is not None and lib.psvo_set_tuning(PSVO_TUNE_BSIM_BWD, int(v)) != PSVO_OK:
+            raise PsvoHipError("PSVO_BSIM_BWD_VARIANT=%s is not a valid psvo_set_tuning value" % v)
         _lib = lib
     return _lib
 

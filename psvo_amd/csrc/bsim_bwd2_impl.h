@@ -26,6 +26,7 @@
 //   accumulator layout of the tile IS the operand layout) and [X' | 1]^T as the A operand; the contraction over lane
 //   groups that the swap-add stages do on the VALU is part of the instruction.
 #pragma once
+#define PSVO_BSIM_BWD_V2_UNIT 1
 #include "bsim_bwd_impl.h"
 
 namespace psvo {
@@ -65,6 +66,38 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 }
 
+// Reduce-scatter of 4 K values over the 16 lanes of a DPP row: on return the four lanes of bank b (lanes 4 b .. 4 b + 3
+// of the row) all hold the row sums of values [b K, (b + 1) K) in out[0 .. K).  The stages over lane bits 3 and 2 need no
+// selects: a DPP add with a bank mask writes only the banks that keep that value (row_ror:8 reads lane ^ 8; row_shl:4 /
+// row_shr:4 read the neighbouring bank), two instructions per pair of values; the last two stages (inside a quad) are
+// all-reduces of the K values that are left.  4 K + 2 K + 2 K instructions against 16 K for a plain all-reduce.
+// (s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states, which hipcc does not insert
+// inside an asm statement.)
+__device__ __forceinline__ float rs_bit3(float lo, float hi) {   // banks 0,1: lo + lo(lane ^ 8);  banks 2,3: hi + hi(lane ^ 8)
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float rs_bit2(float lo, float hi) {   // banks 0,2: lo + lo(lane + 4);  banks 1,3: hi + hi(lane - 4)
+    float r;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+template <int K>
+__device__ __forceinline__ void row_reduce_scatter(const float (&v)[4 * K], float (&out)[K]) {
+    float h[2 * K];
+#pragma unroll
+    for (int i = 0; i < 2 * K; ++i) h[i] = rs_bit3(v[i], v[2 * K + i]);
+#pragma unroll
+    for (int i = 0; i < K; ++i) out[i] = group_sum<4>(rs_bit2(h[i], h[K + i]));
+}
+
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 // JM = 0: per-j sums on the VALU (f2 accumulators + swap-add);  JM = 1: v_mfma_f32_16x16x4_f32
@@ -81,14 +114,16 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     constexpr int CM = CPW * M;           // (chain, m) slots per wave = 32
     constexpr int NF = DX + 2;            // exchange fields per (chain, m): x' (DX), lam2, d Lambda
     constexpr int UVS = (2 * DX + 3) & ~3;   // floats per (chain, m) of the U / V hand-back, padded to float4s
-    constexpr int JC = 8;                 // forward-particle tiles (of 16) per chunk whose per-j sums live in registers
+    // forward-particle tiles (of 16) per chunk whose per-j sums live in registers (the MFMA accumulators take four
+    // registers per tile where the VALU form takes NA: half the tiles per chunk keep it inside the 256-VGPR budget)
+    constexpr int JC = JM ? 4 : 8;
     static_assert(CM == 32 && (M % 4) == 0, "two lanes per (chain, m): M in {4, 8, 16, 32}");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NTB = 256, nwv = 4;
     const int B = a.B, T = a.T, N = a.N;
-    const int NP = ((N + 16 * JC - 1) / (16 * JC)) * (16 * JC);   // tile padded (W' = -inf) to whole chunks
+    const int NP = ((N + 127) / 128) * 128;   // tile padded (W' = -inf: zero weight) to whole chunks (128 entries, both forms)
     const int nch = NP / (16 * JC);
     const int b = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
     constexpr int cpb = nwv * CPW;
@@ -444,26 +479,26 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                 }
             }
             // ---- U, V of every item: sum over the 16 forward particles of the row, hand back per (chain, m) -------------
+            // values ordered [sub-particle i][U (DX), V (DX)]: bank i of the row ends up with sub-particle i's sums
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                float o[4][UVS];
+                float vv[4 * 2 * DX], o[UVS];
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
-                    o[0][d] = row_sum16(Ua[r][d].x); o[1][d] = row_sum16(Ua[r][d].y);
-                    o[2][d] = row_sum16(Ub[r][d].x); o[3][d] = row_sum16(Ub[r][d].y);
-                    o[0][DX + d] = row_sum16(Va[r][d].x); o[1][DX + d] = row_sum16(Va[r][d].y);
-                    o[2][DX + d] = row_sum16(Vb[r][d].x); o[3][DX + d] = row_sum16(Vb[r][d].y);
+                    vv[0 * 2 * DX + d] = Ua[r][d].x; vv[1 * 2 * DX + d] = Ua[r][d].y;
+                    vv[2 * 2 * DX + d] = Ub[r][d].x; vv[3 * 2 * DX + d] = Ub[r][d].y;
+                    vv[0 * 2 * DX + DX + d] = Va[r][d].x; vv[1 * 2 * DX + DX + d] = Va[r][d].y;
+                    vv[2 * 2 * DX + DX + d] = Vb[r][d].x; vv[3 * 2 * DX + DX + d] = Vb[r][d].y;
                 }
-                if (j16 == 0) {
+                float red2[2 * DX];
+                row_reduce_scatter<2 * DX>(vv, red2);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                for (int e = 0; e < UVS; ++e) o[e] = e < 2 * DX ? red2[e < 2 * DX ? e : 0] : 0.f;
+                if ((j16 & 3) == 0) {        // one lane per bank: sub-particle i = j16 >> 2 of item 4 r + g
+                    float* dst = uw + (4 * (4 * r + g) + (j16 >> 2)) * UVS;
 #pragma unroll
-                        for (int e = 2 * DX; e < UVS; ++e) o[i][e] = 0.f;
-                        float* dst = uw + (4 * (4 * r + g) + i) * UVS;
-#pragma unroll
-                        for (int e = 0; e < UVS; e += 4)
-                            *reinterpret_cast<float4*>(dst + e) = make_float4(o[i][e], o[i][e + 1], o[i][e + 2], o[i][e + 3]);
-                    }
+                    for (int e = 0; e < UVS; e += 4)
+                        *reinterpret_cast<float4*>(dst + e) = make_float4(o[e], o[e + 1], o[e + 2], o[e + 3]);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

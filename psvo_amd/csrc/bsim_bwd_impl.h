@@ -25,7 +25,11 @@
 #include "common.h"
 
 namespace psvo {
+#if defined(PSVO_SECTION_TIMERS) && defined(PSVO_BSIM_BWD_V2_UNIT)
+extern __device__ unsigned long long g_sec_bsim_bwd[32];   // (defined by the v1 translation unit of the diagnostic build)
+#else
 PSVO_TIMERS_DEFINE(bsim_bwd)
+#endif
 
 
 struct BsimBwdArgs {

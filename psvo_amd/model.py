@@ -48,7 +48,10 @@ class StackBiRNN(nn.Module):
                   output concat(fw, bw) (B, T, 2 Dh) of the last layer.
     mode "uni":   tf.nn.static_rnn(MultiRNNCell(y_smoother_f)) (BSim_use_single_RNN, src/SMC/PSVO.py:208-212)
                   -- forward cells only; output (B, T, Dh).
-    On the GPU every layer is ONE persistent launch (psvo_bilstm_forward / psvo_bilstm_backward).
+    On the GPU every layer is ONE persistent launch (psvo_bilstm_forward / psvo_bilstm_backward) and nothing else: a cell
+    width the kernels do not cover (Dh not in 8/16/32/64) raises ValueError from the launch, there is no PyTorch fallback for
+    tensors in HBM.  CPU tensors run torch's LSTM on the re-ordered TF weights: the host-side mirror used by the CPU tests of
+    the host logic on a machine without a GPU, never part of the GPU path.
     """
 
     def __init__(self, Din, Dhs, name, mode="stack"):

@@ -39,11 +39,38 @@ class MLP_transformation(nn.Module):
         self.mu_kernel = nn.Parameter(_he_normal_(torch.empty(d, Dout)))   # mu_layer: Dense(linear)
         self.mu_bias = nn.Parameter(torch.zeros(Dout))
 
+    # limits of the native row kernels (psvo_rows_mlp_*, csrc/rows_mlp.hip)
+    _NATIVE_H, _NATIVE_DIN, _NATIVE_DOUT = (16, 32, 64), 128, 4
+
+    def _native_refusal(self, Input):
+        """why psvo_rows_mlp_* cannot evaluate this MLP on `Input` (None if it can)"""
+        if len(self.Dhs) != 1:
+            return "%d hidden layers %s (the native kernels take exactly one)" % (len(self.Dhs), self.Dhs)
+        if self.use_residual:
+            return "use_residual=True"
+        if self.Dhs[0] not in self._NATIVE_H:
+            return "hidden width %d not in %s" % (self.Dhs[0], self._NATIVE_H)
+        if Input.shape[-1] > self._NATIVE_DIN:
+            return "input width %d > %d" % (Input.shape[-1], self._NATIVE_DIN)
+        if self.mu_kernel.shape[1] > self._NATIVE_DOUT:
+            return "output width %d > %d" % (self.mu_kernel.shape[1], self._NATIVE_DOUT)
+        if Input.dtype != torch.float32:
+            return "dtype %s (float32 only)" % Input.dtype
+        return None
+
     def transform(self, Input):
-        """reference MLP.py:48-68; returns (mu, None)."""
-        if (Input.is_cuda and len(self.Dhs) == 1 and not self.use_residual and self.Dhs[0] in (16, 32, 64)
-                and Input.shape[-1] <= 128 and self.mu_kernel.shape[1] <= 4 and Input.dtype == torch.float32):
-            # one native launch forward, one backward (psvo_rows_mlp_*) instead of ~5 + ~15 torch kernels
+        """reference MLP.py:48-68; returns (mu, None).
+
+        Tensors in HBM go through the native row kernels (one launch forward, one backward) or not at all: a shape the
+        kernels do not cover raises ValueError -- there is no PyTorch-op fallback on the GPU.  CPU tensors take the plain
+        matmul form below; that is the host-side mirror the CPU tests of the host logic (encoder wiring, k-step
+        prediction, R-square) run on a machine without a GPU, never part of the GPU path."""
+        if Input.is_cuda:
+            why = self._native_refusal(Input)
+            if why is not None:
+                raise ValueError("%s: no native kernel for this MLP on the GPU: %s (no PyTorch fallback exists; "
+                                 "limits: one hidden layer of %s units, <= %d inputs, <= %d outputs)"
+                                 % (self.name, why, self._NATIVE_H, self._NATIVE_DIN, self._NATIVE_DOUT))
             from ..autograd import RowsMLPFunction
             X = Input.reshape(-1, Input.shape[-1])
             mu = RowsMLPFunction.apply(self.__dict__.get("_flat_grad"), X, self.kernels[0], self.biases[0],
