@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     constexpr int UVS = (2 * DX + 3) & ~3;   // floats per (chain, m) of the U / V hand-back, padded to float4s
     // forward-particle tiles (of 16) per chunk whose per-j sums live in registers (the MFMA accumulators take four
     // registers per tile where the VALU form takes NA: half the tiles per chunk keep it inside the 256-VGPR budget)
-    constexpr int JC = JM ? 4 : 8;
+    constexpr int JC = (JM || DX >= 3) ? 4 : 8;   // (Dx >= 3: the per-(chain, m) sums of both rounds take 16 Dx registers)
     static_assert(CM == 32 && (M % 4) == 0, "two lanes per (chain, m): M in {4, 8, 16, 32}");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -183,8 +183,10 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
         im[d] = a.imean[b * DX + d];
         mi[d] = a.minit[b * DX + d];
     }
-    keep_in_vgpr(isf); keep_in_vgpr(rp); keep_in_vgpr(isfk); keep_in_vgpr(isg); keep_in_vgpr(ikap2);
-    keep_in_vgpr(pc); keep_in_vgpr(pic); keep_in_vgpr(pi1); keep_in_vgpr(pi2);
+    if constexpr (DX <= 2) {
+        keep_in_vgpr(isf); keep_in_vgpr(rp); keep_in_vgpr(isfk); keep_in_vgpr(isg); keep_in_vgpr(ikap2);
+        keep_in_vgpr(pc); keep_in_vgpr(pic); keep_in_vgpr(pi1); keep_in_vgpr(pi2);
+    }
     // (s_init, is_init, i_isig, im, mi are read in the first / last step only: scalar registers)
     const float ninf = -__builtin_huge_valf();
     const float aw = valid ? a.dscore[(size_t)b * N + n] : 0.f;  // d loss / d score of this chain
