@@ -68,11 +68,6 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
     constexpr bool kRolled = (2 * MQ::kSize + MG::kSize) > 330;
     constexpr bool kPeel = (DX <= 3);   // (the Dx = 4 kernel measured slower peeled: C5 14.4 -> 17.6 ms)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // (null checks of optional arrays as flags: the pointers themselves are re-read at their uses, see PSVO_ARG)
-    const bool has_mu1_all = a.mu1_all != nullptr;
-    const bool has_lam2_all = a.lam2_all != nullptr;
-    const bool has_om_all = a.om_all != nullptr;
-    const bool has_sel_in = a.sel_in != nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int NTB = blockDim.x;
@@ -148,15 +143,15 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
     float st[kMaxStage][DX + 1], st_l = 0.f;
     auto stage_load = [&](int tt) {  // global -> registers (raw), forward step tt
         const size_t tb = (size_t)tt * B + b;
-        st_l = PSVO_ARG(BsimArgs, lse)[tb];
+        st_l = a.lse[tb];
 #pragma unroll
         for (int r = 0; r < kMaxStage; ++r) {
             const int j = tid + r * NTB;
             if (j < NP) {
                 const int jc = j < N ? j : N - 1;
 #pragma unroll
-                for (int d = 0; d < DX; ++d) st[r][d] = PSVO_ARG(BsimArgs, Fm)[(tb * DX + d) * N + jc];
-                st[r][DX] = PSVO_ARG(BsimArgs, logW)[tb * N + jc];
+                for (int d = 0; d < DX; ++d) st[r][d] = a.Fm[(tb * DX + d) * N + jc];
+                st[r][DX] = a.logW[tb * N + jc];
             }
         }
     };
@@ -196,13 +191,13 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         const size_t tb = (size_t)t * B + b;
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            e[d] = PSVO_ARG(BsimArgs, eps_b)[((tb * DX + d) * N + n) * M + m];
-            bm[d] = PSVO_ARG(BsimArgs, bmu2)[tb * DX + d];
+            e[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
+            bm[d] = a.bmu2[tb * DX + d];
         }
 #pragma unroll
-        for (int k = 0; k < DY; ++k) o[k] = PSVO_ARG(BsimArgs, obs)[tb * DY + k];
-        if (has_sel_in) ss = PSVO_ARG(BsimArgs, sel_in)[tb * N + n];
-        else uu = PSVO_ARG(BsimArgs, u_b)[tb * N + n];
+        for (int k = 0; k < DY; ++k) o[k] = a.obs[tb * DY + k];
+        if (a.sel_in) ss = a.sel_in[tb * N + n];
+        else uu = a.u_b[tb * N + n];
     };
     load_inputs(T - 1, eps_c, bmu_c, obs_c, u_c, sel_c);
     __syncthreads();
@@ -239,9 +234,9 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
                 x[d] = fmaf(s_init[d], eps_c[d], mu[d]);
             }
             q_lp = diag_lp<DX>(x, mu, is_init, kinit);
-            if (has_mu1_all && valid && lead) {
+            if (a.mu1_all && valid && lead) {
 #pragma unroll
-                for (int d = 0; d < DX; ++d) PSVO_ARG(BsimArgs, mu1_all)[(tb * DX + d) * N + n] = 0.f;
+                for (int d = 0; d < DX; ++d) a.mu1_all[(tb * DX + d) * N + n] = 0.f;
             }
         } else {
             float m1[DX], mu[DX];
@@ -251,9 +246,9 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) m1[d] = group_sum<kQS>(m1[d]);
             }
-            if (has_mu1_all && valid && lead) {
+            if (a.mu1_all && valid && lead) {
 #pragma unroll
-                for (int d = 0; d < DX; ++d) PSVO_ARG(BsimArgs, mu1_all)[(tb * DX + d) * N + n] = m1[d];
+                for (int d = 0; d < DX; ++d) a.mu1_all[(tb * DX + d) * N + n] = m1[d];
             }
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
@@ -395,7 +390,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
             }
             const float lam2 = lm + log2_fast(ls);
             lam = fmaf(kLn2, lam2, kf);
-            if (has_lam2_all && valid && hpart == 0) PSVO_ARG(BsimArgs, lam2_all)[(tb * N + n) * M + m] = lam2;
+            if (a.lam2_all && valid && hpart == 0) a.lam2_all[(tb * N + n) * M + m] = lam2;
         } else {
             lam = diag_lp<DX>(x, im, i_isig, kiota);  // t = 0: q0 / f density at mu_0 (PSVO.py:169-175)
         }
@@ -408,9 +403,9 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         const float cdfv = group_incl_scan<M>(pw, m);  // inclusive scan across the chain's M lanes
         const float total = __shfl(cdfv, gbase + M - 1);
         const float omega = om_raw - fmaf(kLn2, log2_fast(total), omx);
-        if (has_om_all && valid && hpart == 0) PSVO_ARG(BsimArgs, om_all)[(tb * N + n) * M + m] = omega;
+        if (a.om_all && valid && hpart == 0) a.om_all[(tb * N + n) * M + m] = omega;
         int sel;
-        if (has_sel_in) {
+        if (a.sel_in) {
             sel = sel_c;
         } else {
             const unsigned long long bal = __ballot(cdfv <= u_c * total);
@@ -431,12 +426,12 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
 
         if (valid && lead) {
 #pragma unroll
-            for (int d = 0; d < DX; ++d) PSVO_ARG(BsimArgs, bwX)[(tb * DX + d) * N + n] = xs[d];
-            PSVO_ARG(BsimArgs, glp)[tb * N + n] = g_s;
-            PSVO_ARG(BsimArgs, Omega)[tb * N + n] = Om;
-            PSVO_ARG(BsimArgs, sel_out)[tb * N + n] = sel;
-            if (!last) PSVO_ARG(BsimArgs, flp)[(tb + B) * N + n] = phi_s;     // f_log_probs[t+1]
-            if (tzero) PSVO_ARG(BsimArgs, flp)[(size_t)b * N + n] = lam_s;    // f_log_probs[0] = f_init
+            for (int d = 0; d < DX; ++d) a.bwX[(tb * DX + d) * N + n] = xs[d];
+            a.glp[tb * N + n] = g_s;
+            a.Omega[tb * N + n] = Om;
+            a.sel_out[tb * N + n] = sel;
+            if (!last) a.flp[(tb + B) * N + n] = phi_s;     // f_log_probs[t+1]
+            if (tzero) a.flp[(size_t)b * N + n] = lam_s;    // f_log_probs[0] = f_init
         }
         score += g_s - Om + (last ? 0.f : phi_s) + (tzero ? lam_s : 0.f);
 

@@ -398,10 +398,6 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
     using AC = FAcc<DX, DY>;
     constexpr int P = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // (null checks of optional arrays as flags: the pointers themselves are re-read at their uses, see PSVO_ARG)
-    const bool has_dFm_ext = a.dFm_ext != nullptr;
-    const bool has_dlogW_ext = a.dlogW_ext != nullptr;
-    const bool has_dlse = a.dlse != nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NT = blockDim.x, nw = NT >> 6;
@@ -451,7 +447,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
         fm0r[d] = a.fm0[b * DX + d];
     }
     auto load_anc = [&](int t) -> int {
-        return (t >= 1 && a.resample) ? PSVO_ARG(FilterBwdArgs, idx)[((size_t)(t - 1) * B + b) * N + n] : n;
+        return (t >= 1 && a.resample) ? a.idx[((size_t)(t - 1) * B + b) * N + n] : n;
     };
     const bool one_part = (a.nparts == 1);
     // issue-only prefetch (see filter_bwd_kernel)
@@ -461,17 +457,17 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
         const size_t tp = (t == 0) ? tb : tb - B;
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            sx[d] = PSVO_ARG(FilterBwdArgs, X)[(tb * DX + d) * N + n];
-            se[d] = PSVO_ARG(FilterBwdArgs, eps)[(tb * DX + d) * N + n];
-            sm2[d] = a.two_q ? PSVO_ARG(FilterBwdArgs, mu2)[tb * DX + d] : 0.f;
-            sfmean[d] = PSVO_ARG(FilterBwdArgs, Fm)[(tp * DX + d) * N + anc];
-            smean1[d] = a.bootstrap ? 0.f : PSVO_ARG(FilterBwdArgs, P1)[(tp * DX + d) * N + anc];
-            if (has_dFm_ext) {
+            sx[d] = a.X[(tb * DX + d) * N + n];
+            se[d] = a.eps[(tb * DX + d) * N + n];
+            sm2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
+            sfmean[d] = a.Fm[(tp * DX + d) * N + anc];
+            smean1[d] = a.bootstrap ? 0.f : a.P1[(tp * DX + d) * N + anc];
+            if (a.dFm_ext) {
                 if (one_part) {
-                    sdfm[d] = PSVO_ARG(FilterBwdArgs, dFm_ext)[(tb * DX + d) * N + n];
+                    sdfm[d] = a.dFm_ext[(tb * DX + d) * N + n];
                 } else {
                     float ext = 0.f;
-                    for (int q = 0; q < a.nparts; ++q) ext += PSVO_ARG(FilterBwdArgs, dFm_ext)[((tb * a.nparts + q) * DX + d) * N + n];
+                    for (int q = 0; q < a.nparts; ++q) ext += a.dFm_ext[((tb * a.nparts + q) * DX + d) * N + n];
                     sdfm[d] = ext;
                 }
             } else {
@@ -479,16 +475,16 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
             }
         }
 #pragma unroll
-        for (int k = 0; k < DY; ++k) sy[k] = PSVO_ARG(FilterBwdArgs, obs)[tb * DY + k];
-        ssc[0] = PSVO_ARG(FilterBwdArgs, logW)[tb * N + n];
-        ssc[1] = PSVO_ARG(FilterBwdArgs, lse)[tb];
-        ssc[2] = has_dlse ? PSVO_ARG(FilterBwdArgs, dlse)[tb] : 0.f;
-        if (has_dlogW_ext) {
+        for (int k = 0; k < DY; ++k) sy[k] = a.obs[tb * DY + k];
+        ssc[0] = a.logW[tb * N + n];
+        ssc[1] = a.lse[tb];
+        ssc[2] = a.dlse ? a.dlse[tb] : 0.f;
+        if (a.dlogW_ext) {
             if (one_part) {
-                ssc[3] = PSVO_ARG(FilterBwdArgs, dlogW_ext)[tb * N + n];
+                ssc[3] = a.dlogW_ext[tb * N + n];
             } else {
                 float ext = 0.f;
-                for (int q = 0; q < a.nparts; ++q) ext += PSVO_ARG(FilterBwdArgs, dlogW_ext)[(tb * a.nparts + q) * N + n];
+                for (int q = 0; q < a.nparts; ++q) ext += a.dlogW_ext[(tb * a.nparts + q) * N + n];
                 ssc[3] = ext;
             }
         } else {
@@ -564,7 +560,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
                 const float z = (y[k] - gm[k]) * isg[k];
                 dgm[k] = dlw * z * isg[k] * dmean;
                 acc[AC::kSg + k] += cnt * dlw * (z * z - 1.f) * isg[k];
-                if (valid && p == 2) PSVO_ARG(FilterBwdArgs, dG)[(tb * DY + k) * N + n] = dgm[k];
+                if (valid && p == 2) a.dG[(tb * DY + k) * N + n] = dgm[k];
             }
             MG::template bwd_input_part<P>(wg, p, x, dgm, dxp);
         }
@@ -606,10 +602,10 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
         if (valid) {
             if (p == 0) {
 #pragma unroll
-                for (int d = 0; d < DX; ++d) PSVO_ARG(FilterBwdArgs, dP)[(tb * DX + d) * N + n] = dPn[d];
+                for (int d = 0; d < DX; ++d) a.dP[(tb * DX + d) * N + n] = dPn[d];
             } else if (p == 1 && !a.bootstrap) {
 #pragma unroll
-                for (int d = 0; d < DX; ++d) PSVO_ARG(FilterBwdArgs, dF)[(tb * DX + d) * N + n] = dFn[d];
+                for (int d = 0; d < DX; ++d) a.dF[(tb * DX + d) * N + n] = dFn[d];
             }
         }
         MQ::template bwd_input_part<P>(wq1, p, x, dPn, dxp);
@@ -627,7 +623,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
                 inc[AC::kSmm1 + d] += dmu * mean1[d];
                 inc[AC::kSmb + d] += dmu * m2[d];
                 inc[AC::kSmm + d] += dmu * mu[d];
-                if (valid && p == 3) PSVO_ARG(FilterBwdArgs, dm2_rows)[(tb * DX + d) * N + n] = dm2;
+                if (valid && p == 3) a.dm2_rows[(tb * DX + d) * N + n] = dm2;
             } else {
                 dmean1[d] = dmu;
             }

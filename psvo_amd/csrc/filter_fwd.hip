@@ -309,9 +309,6 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
     constexpr int P = 4;
     constexpr bool kOpaque = false;   // (every instantiated shape keeps its weight slice in VGPRs without scratch)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // (null checks of optional arrays as flags: the pointers themselves are re-read at their uses, see PSVO_ARG)
-    const bool has_idx_in = a.idx_in != nullptr;
-    const bool has_P1 = a.P1 != nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NT = blockDim.x, nw = NT >> 6;
@@ -373,14 +370,14 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         const size_t tb = (size_t)t * B + b;
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            e[d] = PSVO_ARG(FilterArgs, eps)[(tb * DX + d) * N + n];
-            m[d] = a.two_q ? PSVO_ARG(FilterArgs, mu2)[tb * DX + d] : 0.f;
+            e[d] = a.eps[(tb * DX + d) * N + n];
+            m[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < DY; ++k) o[k] = PSVO_ARG(FilterArgs, obs)[tb * DY + k];
+        for (int k = 0; k < DY; ++k) o[k] = a.obs[tb * DY + k];
         if (a.resample) {
-            if (has_idx_in) ii = PSVO_ARG(FilterArgs, idx_in)[tb * N + n];
-            else uu = PSVO_ARG(FilterArgs, u)[tb * N + n];
+            if (a.idx_in) ii = a.idx_in[tb * N + n];
+            else uu = a.u[tb * N + n];
         }
     };
     load_inputs(0, eps_c, mu2_c, obs_c, u_c, idx_c);
@@ -436,14 +433,14 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         if (valid) {   // history: one lane of the quad per array
             if (p == 0) {
 #pragma unroll
-                for (int d = 0; d < DX; ++d) PSVO_ARG(FilterArgs, X)[(tb * DX + d) * N + n] = x[d];
-                PSVO_ARG(FilterArgs, logW)[tb * N + n] = lw;
+                for (int d = 0; d < DX; ++d) a.X[(tb * DX + d) * N + n] = x[d];
+                a.logW[tb * N + n] = lw;
             } else if (p == 1) {
 #pragma unroll
-                for (int d = 0; d < DX; ++d) PSVO_ARG(FilterArgs, Fm)[(tb * DX + d) * N + n] = fm[d];
-            } else if (p == 2 && has_P1) {
+                for (int d = 0; d < DX; ++d) a.Fm[(tb * DX + d) * N + n] = fm[d];
+            } else if (p == 2 && a.P1) {
 #pragma unroll
-                for (int d = 0; d < DX; ++d) PSVO_ARG(FilterArgs, P1)[(tb * DX + d) * N + n] = p1[d];
+                for (int d = 0; d < DX; ++d) a.P1[(tb * DX + d) * N + n] = p1[d];
             }
         }
 
@@ -484,7 +481,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         const float off = uwave > 0 ? lane_bcast(pre, max(uwave - 1, 0)) : 0.f;   // sum over the waves before this one
         sc = fmaf(sc, exp2_fast((wbase - gbase) * kLog2e), off);
         const float lse_t = fmaf(kLn2, log2_fast(total), gmx);
-        if (tid == 3) PSVO_ARG(FilterArgs, lse)[tb] = lse_t;
+        if (tid == 3) a.lse[tb] = lse_t;
 
         SEC(6);   // cross-wave combination
         if (a.resample) {
@@ -495,7 +492,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
             __syncthreads();
             SEC(7);   // cdf store + barrier
             int idx;
-            if (has_idx_in) {
+            if (a.idx_in) {
                 idx = idx_c;
             } else {
                 // idx = #{k : cdf[k] <= u * total} (SVO.py:266-300 as defined in the oracle), two 16-ary rounds
@@ -518,10 +515,10 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
                 fmean[d] = a.bootstrap ? mean1[d] : sf[d * NPT + idx];
             }
             if (valid) {
-                if (p == 3) PSVO_ARG(FilterArgs, idx_out)[tb * N + n] = idx;
+                if (p == 3) a.idx_out[tb * N + n] = idx;
                 if (p == 0) {
 #pragma unroll
-                    for (int d = 0; d < DX; ++d) PSVO_ARG(FilterArgs, Xanc)[(tb * DX + d) * N + n] = x[d];
+                    for (int d = 0; d < DX; ++d) a.Xanc[(tb * DX + d) * N + n] = x[d];
                 }
             }
             lnw = neg_logN;
@@ -535,10 +532,10 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
                 fmean[d] = fm[d];
             }
             if (valid) {
-                if (p == 3) PSVO_ARG(FilterArgs, idx_out)[tb * N + n] = n;
+                if (p == 3) a.idx_out[tb * N + n] = n;
                 if (p == 0) {
 #pragma unroll
-                    for (int d = 0; d < DX; ++d) PSVO_ARG(FilterArgs, Xanc)[(tb * DX + d) * N + n] = x[d];
+                    for (int d = 0; d < DX; ++d) a.Xanc[(tb * DX + d) * N + n] = x[d];
                 }
             }
             lnw = lw - lse_t;

@@ -9,7 +9,7 @@
 // Unlike PSVO, sum_m d Lambda_m = a != 0, so the normalisation of the forward weights does receive gradient:
 // d lse[t-1] = - sum_j d W^_j is written for psvo_filter_backward.
 // The cross-chain resampling (bwXanc_t[k] = bwX_t[anc_t[k]]) back-propagates as a scatter-add of
-// d bwXanc_t into the selected sub-particle of the parent chain (LDS float atomics, N*Dx per step).
+// d bwXanc_t into the selected sub-particle of the parent chain (fixed summation order, N*Dx per step).
 // The forward tile is recomputed (second pass) exactly as in bsim_bwd_impl.h: per-j partial sums are
 // reduce-scattered over the 16 quads of a wave with a butterfly, folded over waves through LDS and written as
 // per-workgroup partials; sums over chains (d bmu2, d minit, d imean) are left to the host as per-chain rows.
@@ -127,6 +127,8 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
     float* jacc = tile + 2 * NP * PS;           // [nw][NA][NP] wave-private d F' / d W^ sums of the step
     float* dxs = jacc + nw * NA * NP;           // [DX][Nc] d loss / d (selected sub-particle) of the own chains
     float* red = dxs + DX * Nc;                 // 64
+    float* xval = red + 64;                     // [DX][N] polled d loss / d bwXanc_t of chain k (if its parent is ours)
+    int* xpar = reinterpret_cast<int*>(xval + DX * N);   // [N] parent of chain k relative to c0, or -1
 
     MQ::load(wf, a.f, tid, NTB);
     MG::load(wg, a.g, tid, NTB);
@@ -466,6 +468,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
                     const unsigned tag = (unsigned)(t + 1);
                     for (int k = tid; k < N; k += NTB) {
                         const int p = a.anc[tb * N + k];
+                        xpar[k] = (p >= c0 && p < c1) ? p - c0 : -1;
                         if (p >= c0 && p < c1) {   // poll chain k's words (its owner wrote them during step t-1; bounded spin)
                             const unsigned long long* const w = slot + (size_t)k * kWbWords;
                             unsigned spins = 0;
@@ -479,8 +482,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
                                 }
                                 if (ok) {
 #pragma unroll
-                                    for (int d = 0; d < DX; ++d)
-                                        atomicAdd(&dxs[d * Nc + (p - c0)], __uint_as_float((unsigned)v[d]));
+                                    for (int d = 0; d < DX; ++d) xval[d * N + k] = __uint_as_float((unsigned)v[d]);
                                     break;
                                 }
                                 __builtin_amdgcn_s_sleep(1);
@@ -492,6 +494,23 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
                                 }
                             }
                         }
+                    }
+                    // scatter-add into the parents in a FIXED order (the gradients are then reproducible bit for bit between
+                    // launches, eager or replayed; LDS float atomics are not): S lanes per (parent, d) walk the children
+                    // k = s, s + S, ... in ascending order and are folded by a fixed xor tree
+                    __syncthreads();
+                    {
+                        const int pairs = DX * Nc;
+                        int S = 1;
+                        while (S < 16 && 2 * S * pairs <= NTB) S <<= 1;
+                        const int pr = tid / S, sl = tid % S;
+                        float acc_s = 0.f;
+                        if (pr < pairs) {
+                            const int d = pr / Nc, pl = pr - d * Nc;
+                            for (int k = sl; k < N; k += S) acc_s += (xpar[k] == pl) ? xval[d * N + k] : 0.f;
+                        }
+                        for (int msk = 1; msk < S; msk <<= 1) acc_s += __shfl_xor(acc_s, msk);
+                        if (pr < pairs && sl == 0) dxs[pr] = acc_s;
                     }
                 }
                 __syncthreads();
@@ -654,7 +673,7 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
     if (NTB > 512) NTB = 512;
     const int nw = NTB / 64;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nw * (DX + 1) * NP +
-                                        (size_t)DX * Nc + 64);
+                                        (size_t)DX * Nc + 64 + (size_t)(DX + 1) * a.N);
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
     // tags of an earlier launch must not be mistaken for this one's: clear the ring and the error flag

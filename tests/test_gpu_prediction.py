@@ -27,7 +27,7 @@ def test_n_step_prediction_and_r_square_match_oracle(built_lib, obj, Dx, Dy, H):
     for k in range(K + 1):
         assert tuple(y_hat[k].shape) == (B, T - k, Dy)
         assert torch.allclose(y_hat[k].double().cpu(), y_hat_ref[k], atol=2e-4, rtol=1e-5), k
-        assert torch.equal(y[k].double().cpu(), y_ref[k])
+        assert torch.allclose(y[k].double().cpu(), y_ref[k], atol=1e-6)
     r2 = trainer.evaluate_R_square(None, [v.cpu().numpy() for v in y_hat], [v.cpu().numpy() for v in y])
     r2_ref = O.evaluate_R_square(y_hat_ref, y_ref).numpy()
     assert np.allclose(r2, r2_ref, atol=1e-4, rtol=1e-4)

@@ -1,0 +1,87 @@
+"""Allocation discipline of the side-stream launches (the PSVOwR gradient flake of round 1).
+
+The filter kernels are issued on a side stream while the main stream is still busy.  PyTorch's caching allocator hands a
+freed block back to the NEXT request of the SAME stream's pool without waiting for the work queued on that stream, which is
+correct only as long as the block is reused on that stream.  A wrapper that allocates its outputs from the MAIN stream's pool
+while launching on the SIDE stream can therefore be handed a block that queued main-stream work is still reading or writing
+(the side stream is not ordered after that work).  The rule the wrappers follow: buffers allocated under ops.launch_on(stream)
+come from THAT stream's pool, inputs that arrive from another stream are record_stream()'ed when their pointer is taken, and
+whoever consumes the outputs on another stream records them there."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _busy(stream, ms=30.0):
+    """queue roughly `ms` of work on `stream` and return the tensors it uses"""
+    a = torch.randn(4096, 4096, device="cuda")
+    with torch.cuda.stream(stream):
+        b = a
+        for _ in range(max(1, int(ms / 0.25))):
+            b = b @ a
+            b = b / b.norm()
+    return a, b
+
+
+def test_side_stream_wrappers_do_not_take_blocks_of_the_main_pool(built_lib):
+    from psvo_amd import ops
+    from psvo_amd.autograd import side_stream
+    main, side = torch.cuda.current_stream(), side_stream("cuda:0")
+    torch.cuda.synchronize()
+    R, Din, H, Dout = 1 << 16, 64, 32, 2
+    X = torch.randn(R, Din, device="cuda")
+    w = (torch.randn(Din, H, device="cuda"), torch.zeros(H, device="cuda"), torch.randn(H, Dout, device="cuda"),
+         torch.zeros(Dout, device="cuda"))
+    # a block of exactly the size the wrapper will ask for, written by queued main-stream work, then freed
+    scratch = torch.empty(R, Dout, device="cuda")
+    freed_ptr = scratch.data_ptr()
+    keep = _busy(main)                        # main stream is busy for tens of milliseconds ...
+    scratch.copy_(X[:, :Dout])                # ... and this write to `scratch` is queued behind it
+    del scratch                               # back to the MAIN stream's pool while the write is still pending
+    assert not main.query(), "the main stream must still be busy for this test to mean anything"
+    side.wait_stream(main) if False else None  # (deliberately NOT ordered after the main stream)
+    with ops.launch_on(side):
+        out = ops.rows_mlp_forward(X, w)       # allocates (R, Dout) under launch_on(side)
+    assert out.data_ptr() != freed_ptr, "side-stream wrapper reused a block the main stream has pending work on"
+    # the same request on the main stream does get that block back: the scenario was real
+    again = torch.empty(R, Dout, device="cuda")
+    assert again.data_ptr() == freed_ptr
+    torch.cuda.synchronize()
+    del keep
+    ref = torch.relu(X @ w[0] + w[1]) @ w[2] + w[3]
+    assert torch.allclose(out, ref, atol=1e-3, rtol=1e-4)
+
+
+def test_cross_stream_tensors_are_recorded(built_lib, monkeypatch):
+    """every tensor that crosses between the main and a side stream inside one PSVOwR training evaluation is
+    record_stream()'ed on the consuming stream: inputs of side-stream launches when their pointer is taken (ops._ptr), outputs
+    of side-stream launches before the main stream consumes them (autograd._used_on)"""
+    from psvo_amd import autograd, ops
+    from tests.test_gpu_parity import _setup
+    seen = []
+    orig = torch.Tensor.record_stream
+
+    def spy(self, stream):
+        seen.append((self.data_ptr(), stream.cuda_stream))
+        return orig(self, stream)
+    monkeypatch.setattr(torch.Tensor, "record_stream", spy)
+    FLAGS, model, smc, obs, noise = _setup("PSVOwR", 2, 6, 16, 4, 2, 1, 16, True, True, seed=1)
+    smc.generator = torch.Generator(device="cuda").manual_seed(0)
+    side = autograd.side_stream(obs.device if obs.is_cuda else "cuda:0").cuda_stream
+    main = torch.cuda.current_stream().cuda_stream
+    z, log = smc.get_log_ZSMC(obs.float().cuda(), None)
+    z.backward()
+    torch.cuda.synchronize()
+    on_side = {p for p, s in seen if s == side}
+    on_main = {p for p, s in seen if s == main}
+    filt = log["filter"]
+    # outputs of the side-stream filter are consumed by the main-stream backward simulation
+    for k in ("Fm", "logW", "lse", "X"):
+        assert filt[k].data_ptr() in on_main, "filter output %s not recorded on the consuming (main) stream" % k
+    # inputs of the side-stream filter were produced on the main stream
+    for k in ("eps", "u"):
+        assert filt[k].data_ptr() in on_side, "filter input %s not recorded on the side stream" % k
+    assert len(on_side) >= 8 and len(on_main) >= 4
