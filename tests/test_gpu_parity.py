@@ -431,9 +431,10 @@ def test_short_sequences(built_lib, obj, T, N):
 
 def test_psvowr_step_replays_from_hipgraph(built_lib):
     """The PSVOwR kernels are cooperative launches (a cluster of workgroups per sequence exchanges data through HBM).
-    Captured into a hipGraph and replayed, the local step must give the eagerly issued one's value AND gradients bit for bit
-    (every reduction of the path has a fixed order, the reverse kernel's cross-chain scatter-add included; fixed injected
-    noise), replay after replay, and no exchange poll may time out."""
+    Captured into a hipGraph and replayed, the local step must give the eagerly issued one's value bit for bit and its
+    gradients to rounding (the PSVOwR reverse kernel's cross-chain scatter-add has a fixed order since round 2, but the
+    filter's reverse pass still scatter-adds the resampling gather's gradient with LDS float atomics, whose order is not
+    fixed; fixed injected noise), replay after replay, and no exchange poll may time out."""
     from psvo_amd.graph import GraphedStep
     from psvo_amd.optim import FlatParams
     FLAGS, model, smc, obs, noise = _setup("PSVOwR", 4, 12, 64, 8, 2, 1, 32, True, True, seed=3)
@@ -458,7 +459,7 @@ def test_psvowr_step_replays_from_hipgraph(built_lib):
         torch.cuda.synchronize()
         assert torch.equal(z_g, z_e)
         assert torch.isfinite(flat.grad).all()
-        assert torch.equal(flat.grad, g_e)      # (the reverse kernel's cross-chain scatter-add has a fixed order)
+        assert (flat.grad - g_e).abs().max() <= 1e-5 * float(g_e.abs().max())
     smc.check_exchange()
 
 
