@@ -232,9 +232,10 @@ def main():
     ap.add_argument("--cpu-sample-T", type=int, default=40)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--bsim-bwd-variant", type=int, default=-1, choices=[-1, 0, 1, 2],
+    ap.add_argument("--bsim-bwd-variant", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="A/B switch of the reverse backward-simulation kernel (psvo_set_tuning, include/psvo_hip.h): "
-                         "0 = v1 butterflies, 1 = v2 VALU, 2 = v2 with the per-j sums on f32 MFMA, -1 = library default")
+                         "0 = v1 butterflies, 1 = v2 VALU, 2 = v2 with the per-j sums on f32 MFMA, 3 = v2 with the pair exponents on f32 "
+                         "MFMA, -1 = library default")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -438,13 +439,13 @@ def main():
         # figure is the committed, calibrated FETCH_SIZE / WRITE_SIZE measurement of the same workload
         # (tools/traffic_probe.py + tools/traffic_report.py -> profiles/r01_hbm_traffic_Cstar.json), else null
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic_Cstar.json")
+        tp = os.path.join(ROOT, "profiles", "r02_hbm_traffic_Cstar.json")
         if args.workload == "C*" and os.path.exists(tp):
-            key = {"psvo_bsim_backward": "bsim_bwd_kernel", "psvo_bsim_forward": "bsim_fwd_kernel",
+            key = {"psvo_bsim_backward": "bsim_bwd", "psvo_bsim_forward": "bsim_fwd_kernel",
                    "psvo_filter_backward": "filter_bwd_kernel", "psvo_filter_forward": "filter_fwd"}[dominant]
             for k, v in json.load(open(tp))["kernels"].items():
-                if key in k:
-                    traffic, traffic_src = v["hbm_MB_per_launch"] * 1e6, "profiles/r01_hbm_traffic_Cstar.json"
+                if key in k and "finalize" not in k and v["hbm_MB_per_launch"] * 1e6 > (traffic or 0.0):
+                    traffic, traffic_src = v["hbm_MB_per_launch"] * 1e6, "profiles/r02_hbm_traffic_Cstar.json"
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -461,14 +462,15 @@ def main():
                        "bsim_bwd_variant": args.bsim_bwd_variant,
                        "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())},
                        "native_timeline_ms": timeline},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)",
                          "traffic_source": traffic_src,
                          "kernel": dominant, "kernel_ms_avg": k_avg, "flop_per_particle_step": f_dom,
                          "exp_frac": (units * x_bsim / (k_avg * 1e-3) / EXP_PEAK) if "bsim" in dominant else None,
-                         "note": "fp32 VALU + transcendental work, not GEMM-shaped (K = Dx <= 4): priced against the "
-                                 "f32 peak (f32-input MFMA dense peak == f32 vector peak = 157.3 TFLOP/s); the path "
-                                 "is serial in t, so it is latency-limited well before this ceiling"},
+                         "note": "bound = the f32 vector ALU (not one of the contract's two labels: the dominant kernel has no "
+                                 "MFMA in its default build and moves 0.5 TB/s): priced against the 157.3 TFLOP/s f32 peak, "
+                                 "which on gfx950 is also the f32-input MFMA peak -- the f32 MFMA variants were measured "
+                                 "beside the VALU kernel and do not co-execute with it (profiles/r02_bsim_bwd_ab.md)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, P_ref, obs.cpu(), min(args.cpu_sample_T, T),

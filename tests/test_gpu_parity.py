@@ -335,12 +335,13 @@ BSIM_BWD_VARIANT_CASES = [c for c in CASES if c[0] == "PSVO"] + [("PSVO", 2, 9, 
                                                                 ("PSVO", 1, 5, 300, 32, 4, 2, 16, True, True)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", BSIM_BWD_VARIANT_CASES, ids=lambda c: "-".join(map(str, c)))
 def test_bsim_backward_variants(built_lib, case, variant):
     """psvo_bsim_backward under every PSVO_TUNE_BSIM_BWD setting -- v1 (lane = (chain, half, m), per-j butterflies), v2
-    ("j on lanes", per-j sums in registers + swap-add) and v2 with the per-j sums on v_mfma_f32_16x16x4_f32 -- every
-    gradient against the fp64 oracle's autograd (teacher-forced indices), same tolerance for all three"""
+    ("j on lanes", per-j sums in registers + swap-add), v2 with the per-j sums on v_mfma_f32_16x16x4_f32 and v2 with the pair
+    exponents on v_mfma_f32_16x16x4_f32 (Dx = 2) -- every gradient against the fp64 oracle's autograd (teacher-forced
+    indices), same tolerance for all four"""
     from psvo_amd import _lib
     lib = _lib.load()
     obj = case[0]
@@ -348,6 +349,39 @@ def test_bsim_backward_variants(built_lib, case, variant):
     _, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
     teacher = {"idx_f": ref0["idx_f"], "idx_b": ref0["idx_b"]}
     z_ref, P = _oracle_grads(model, FLAGS, obj, obs, noise, teacher)
+    nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
+    nz.pop("u_f", None); nz.pop("u_b", None)
+    assert lib.psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, variant) == 0
+    try:
+        model.zero_grad()
+        z, _ = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
+        z.backward()
+        torch.cuda.synchronize()
+    finally:
+        lib.psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, -1)
+    assert abs(float(z.detach()) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+    _check_grads(model, P)
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("sigma_f", [1.0, 0.3, 0.1])
+def test_bsim_backward_small_transition_scale(built_lib, variant, sigma_f):
+    """The exponent MFMA of variant 3 forms W' - |x' - F'|^2 as an expanded product (2 x'.F' - |x'|^2 - |F'|^2), which
+    cancels where the differenced VALU form does not; the scaled coordinates grow as 1 / sigma_f.  Gradients at the
+    reference's floor sigma_f = 1 and at 0.3 / 0.1 of it (f_sigma_min lowered) against the fp64 oracle; the VALU variant runs
+    beside it as the control."""
+    from psvo_amd import _lib
+    import math
+    lib = _lib.load()
+    case = ("PSVO", 2, 8, 128, 16, 2, 1, 32, True, True)
+    FLAGS, model, smc, obs, noise = _setup(*case, seed=19, q1_sigma_min=0.01, f_sigma_min=0.01)
+    with torch.no_grad():        # transition scale (f == q1 under use_bootstrap): softplus(raw) = sigma_f
+        model.q1_dist.sigma_con.fill_(math.log(math.expm1(sigma_f)))
+    obs = O.fhn_synthetic(2, 8, seed=5)[1]
+    _, ref0 = Hh.run_oracle(model, FLAGS, "PSVO", obs, noise)
+    teacher = {"idx_f": ref0["idx_f"], "idx_b": ref0["idx_b"]}
+    z_ref, P = _oracle_grads(model, FLAGS, "PSVO", obs, noise, teacher)
+    assert abs(float(O.get_sigma(P["q1"])[0]) - sigma_f) < 1e-6
     nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
     nz.pop("u_f", None); nz.pop("u_b", None)
     assert lib.psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, variant) == 0
