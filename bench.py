@@ -136,10 +136,19 @@ def cpu_baseline(wl, P, obs_cpu, sample_T, threads, train):
 
 
 def elbo_vs_oracle(wl, P, obs_cpu, sample_T, device, threads):
-    """ELBO and smoothed trajectories of the HIP path against the fp64 CPU oracle on identical inputs: the same
-    parameters (the snapshot taken before training), observations and injected noise, first `sample_T` time steps."""
+    """The "ELBO vs ref" half of the metric: the HIP path against the fp64 CPU oracle on identical inputs -- the same
+    parameters (the snapshot taken before training), observations and injected noise, first `sample_T` time steps.
+
+    Two comparisons, because a free-running particle system stops being comparable draw by draw after the first resampling
+    index that differs (an fp32 CDF against an fp64 one flips an index whenever a uniform lands within rounding of an
+    edge; from then on the two runs are different, equally valid, particle systems and their trajectories differ by O(1)):
+      * free-running: the kernels draw their own indices; the oracle is then re-run with THOSE indices teacher-forced, every
+        value must agree, and every index is checked to be the oracle's own inverse-CDF draw or to sit within
+        `worst_edge_distance` (fraction of the total weight) of the CDF edge that separates the two.  `flipped_draws` is
+        the number of indices that differ from the oracle's own draw on the same logits.
+      * the ELBO of the oracle's own free run is reported beside it (`elbo_oracle_free_run`): it agrees to rounding when no
+        index flipped and differs like two independent draws otherwise."""
     from oracle import psvo_oracle as O
-    from psvo_amd.model import SSM
     obj, B, T, N, Dx, Dy, M, H, Dh = wl
     torch.set_num_threads(threads)
     P64 = O.params_to(P, torch.float64)
@@ -148,7 +157,7 @@ def elbo_vs_oracle(wl, P, obs_cpu, sample_T, device, threads):
     obs_s = obs_cpu[:, :sample_T].contiguous().double()
     noise = O.make_noise(fl, B, sample_T, seed=7, dtype=torch.float64)
     with torch.no_grad():
-        z_ref, log_ref = O.OBJECTIVES[obj](P64, fl).get_log_ZSMC(obs_s, noise)
+        z_free, _ = O.OBJECTIVES[obj](P64, fl).get_log_ZSMC(obs_s, noise)
     FLAGS, model, smc = build_objective(wl, device, seed=0)
     model.load_reference_layout(P)
     perm = {"eps_f": (0, 2, 3, 1), "u_f": (0, 2, 1), "eps_b": (0, 3, 4, 2, 1), "u_b": (0, 2, 1), "u_r": (0, 2, 1)}
@@ -156,11 +165,33 @@ def elbo_vs_oracle(wl, P, obs_cpu, sample_T, device, threads):
     with torch.no_grad():
         z, log = smc.get_log_ZSMC(obs_s.float().to(device), None, noise=nz)
     torch.cuda.synchronize()
+    # the oracle with the kernels' own indices teacher-forced, every draw logged
+    teach = {}
+    if log["filter"].get("idx") is not None:
+        teach["idx_f"] = log["filter"]["idx"].permute(0, 2, 1).cpu().long()
+    if obj in ("PSVO", "PSVOwR"):
+        teach["idx_b"] = log["bsim"]["sel"].permute(0, 2, 1).cpu().long()
+    if obj == "PSVOwR":
+        teach["idx_r"] = log["bsim"]["anc"].permute(0, 2, 1).cpu().long()
+    o = O.OBJECTIVES[obj](P64, fl)
+    o.draw_log = []
+    with torch.no_grad():
+        z_ref, log_ref = o.get_log_ZSMC(obs_s, {**noise, **teach})
+    draws = flipped = 0
+    worst = 0.0
+    for log_W, u, idx in o.draw_log:
+        d = O.draw_distance(log_W, u, idx)
+        draws += d.numel()
+        flipped += int((d > 0).sum())
+        worst = max(worst, float(d.max()))
     return {"elbo_hip": float(z), "elbo_oracle": float(z_ref),
             "rel_err": abs(float(z) - float(z_ref)) / abs(float(z_ref)),
             "max_abs_trajectory_err": float((log["Xs"].double().cpu() - log_ref["Xs"]).abs().max()),
+            "draws": draws, "flipped_draws": flipped, "worst_edge_distance": worst,
+            "elbo_oracle_free_run": float(z_free),
             "sample": "first %d of %d time steps of the workload, identical parameters / observations / injected "
-                      "noise, fp64 PyTorch-CPU oracle vs fp32 HIP path (in-kernel multinomial draws)" % (sample_T, T)}
+                      "noise, fp64 PyTorch-CPU oracle vs fp32 HIP path; in-kernel multinomial draws, the oracle re-run "
+                      "with the kernels' indices (every draw verified against the oracle's CDF)" % (sample_T, T)}
 
 
 def _free_port():
