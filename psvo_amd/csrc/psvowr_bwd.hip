@@ -127,8 +127,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
     float* jacc = tile + 2 * NP * PS;           // [nw][NA][NP] wave-private d F' / d W^ sums of the step
     float* dxs = jacc + nw * NA * NP;           // [DX][Nc] d loss / d (selected sub-particle) of the own chains
     float* red = dxs + DX * Nc;                 // 64
-    float* xval = red + 64;                     // [DX][N] polled d loss / d bwXanc_t of chain k (if its parent is ours)
-    int* xpar = reinterpret_cast<int*>(xval + DX * N);   // [N] parent of chain k relative to c0, or -1
+    int* xpar = reinterpret_cast<int*>(red + 64);   // [N] ancestor of chain k at this step, relative to c0
 
     MQ::load(wf, a.f, tid, NTB);
     MG::load(wg, a.g, tid, NTB);
@@ -275,6 +274,8 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
 
         for (int i = tid; i < DX * Nc; i += NTB) dxs[i] = 0.f;
         for (int i = tid; i < nw * NA * NP; i += NTB) jacc[i] = 0.f;
+        if (t >= 1)
+            for (int k = tid; k < N; k += NTB) xpar[k] = a.anc[tb * N + k] - c0;   // parents of this step's gathers
         __syncthreads();
 
         float* ja = jacc + wave * NA * NP;
@@ -466,23 +467,26 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
                 if (t >= 1) {
                     const unsigned long long* const slot = a.ring + ((size_t)t * B + b) * N * kWbWords;
                     const unsigned tag = (unsigned)(t + 1);
-                    for (int k = tid; k < N; k += NTB) {
-                        const int p = a.anc[tb * N + k];
-                        xpar[k] = (p >= c0 && p < c1) ? p - c0 : -1;
-                        if (p >= c0 && p < c1) {   // poll chain k's words (its owner wrote them during step t-1; bounded spin)
-                            const unsigned long long* const w = slot + (size_t)k * kWbWords;
+                    // Scatter-add of the published gradients into the parents this workgroup owns, in a FIXED order (LDS float
+                    // atomics would make the gradients differ from launch to launch): S lanes per (parent, d) walk the
+                    // children k = s, s + S, ... in ascending order, poll the word of every child whose parent is theirs
+                    // (bounded spin; xpar[] = this step's ancestors relative to c0, staged at the top of the step), and are
+                    // folded by a fixed xor tree.  Every word is polled by exactly one lane.
+                    const int pairs = DX * Nc;
+                    const int S = (16 * pairs <= NTB) ? 16 : (8 * pairs <= NTB) ? 8 : (4 * pairs <= NTB) ? 4
+                                                      : (2 * pairs <= NTB) ? 2 : 1;
+                    const int pr = tid / S, sl = tid - pr * S;
+                    float acc_s = 0.f;
+                    if (pr < pairs) {
+                        const int d = pr / Nc, pl = pr - d * Nc;
+                        for (int k = sl; k < N; k += S) {
+                            if (xpar[k] != pl) continue;
+                            const unsigned long long* const w = slot + (size_t)k * kWbWords + d;
                             unsigned spins = 0;
                             for (;;) {
-                                unsigned long long v[DX];
-                                bool ok = true;
-#pragma unroll
-                                for (int d = 0; d < DX; ++d) {
-                                    v[d] = __hip_atomic_load(w + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    ok = ok && (unsigned)(v[d] >> 32) == tag;
-                                }
-                                if (ok) {
-#pragma unroll
-                                    for (int d = 0; d < DX; ++d) xval[d * N + k] = __uint_as_float((unsigned)v[d]);
+                                const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if ((unsigned)(v >> 32) == tag) {
+                                    acc_s += __uint_as_float((unsigned)v);
                                     break;
                                 }
                                 __builtin_amdgcn_s_sleep(1);
@@ -495,23 +499,11 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
                             }
                         }
                     }
-                    // scatter-add into the parents in a FIXED order (the gradients are then reproducible bit for bit between
-                    // launches, eager or replayed; LDS float atomics are not): S lanes per (parent, d) walk the children
-                    // k = s, s + S, ... in ascending order and are folded by a fixed xor tree
-                    __syncthreads();
-                    {
-                        const int pairs = DX * Nc;
-                        int S = 1;
-                        while (S < 16 && 2 * S * pairs <= NTB) S <<= 1;
-                        const int pr = tid / S, sl = tid % S;
-                        float acc_s = 0.f;
-                        if (pr < pairs) {
-                            const int d = pr / Nc, pl = pr - d * Nc;
-                            for (int k = sl; k < N; k += S) acc_s += (xpar[k] == pl) ? xval[d * N + k] : 0.f;
-                        }
-                        for (int msk = 1; msk < S; msk <<= 1) acc_s += __shfl_xor(acc_s, msk);
-                        if (pr < pairs && sl == 0) dxs[pr] = acc_s;
-                    }
+                    if (S >= 2) acc_s += xor_lane<1>(acc_s);
+                    if (S >= 4) acc_s += xor_lane<2>(acc_s);
+                    if (S >= 8) acc_s += xor_lane<4>(acc_s);
+                    if (S >= 16) acc_s += xor_lane<8>(acc_s);
+                    if (pr < pairs && sl == 0) dxs[pr] = acc_s;
                 }
                 __syncthreads();
             }
@@ -673,7 +665,7 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
     if (NTB > 512) NTB = 512;
     const int nw = NTB / 64;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nw * (DX + 1) * NP +
-                                        (size_t)DX * Nc + 64 + (size_t)(DX + 1) * a.N);
+                                        (size_t)DX * Nc + 64 + (size_t)a.N);
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
     // tags of an earlier launch must not be mistaken for this one's: clear the ring and the error flag
