@@ -367,6 +367,20 @@ int psvo_sigma_backward(const float* raw, const float* mins, const float* dsig, 
 
 /* Diagnostic: runs the DPP / permlane cross-lane primitives the kernels are built on over one
  * wavefront of input (64 floats) and writes 9 x 64 results (xor 1..32, inclusive scan, sum, max). */
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers over plain rows on v_mfma_f32_16x16x4_f32 (exact f32): the hoisted networks q0, q2, BSim_q2, BSim_q_init
+ * (reference src/transformation/MLP.py:24-68) when they have more than one hidden layer or exceed psvo_rows_mlp_*'s
+ * widths (Din <= 4096, Dout <= 4096 here).  Rows X (R, Din) row-major, W (Din, Dout) keras layout, b (Dout).
+ *   forward : Y = relu ? max(X W + b, 0) : X W + b
+ *   backward: dZ = relu ? dY * [Y > 0] : dY;  dX = dZ W^T (R, Din; may be null);  grad = [dW (Din, Dout) | db (Dout)],
+ *             accumulated into `grad` when `accumulate`.  partial: psvo_dense_wgrad_slices(R) * (Din + 1) * Dout floats.
+ * ------------------------------------------------------------------------------------------- */
+int psvo_dense_wgrad_slices(long long R);
+int psvo_dense_forward(long long R, int Din, int Dout, const float* X, const float* W, const float* b, int relu,
+                       float* Y, void* stream);
+int psvo_dense_backward(long long R, int Din, int Dout, const float* X, const float* Y, const float* dY, const float* W,
+                        int relu, float* dX, float* partial, float* grad, int accumulate, void* stream);
+
 int psvo_selftest_lanes(const float* in64, float* out576, void* stream);
 /* second self-test: swap-add stages over lane bits 5 / 4, 16-lane row sum, and the operand / accumulator layout of
  * v_mfma_f32_16x16x4_f32 as bsim_bwd2 uses it.  in: 3 x 64 floats (lo, hi, extra); out: 5 x 64 floats

@@ -60,6 +60,10 @@ SIGNATURES = {
     "psvo_rows_mlp_forward": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _MLP, _P, _P]),
     "psvo_rows_mlp_backward": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _MLP,
                                               _P, _P, _P, ctypes.c_int, _P]),
+    "psvo_dense_wgrad_slices": (ctypes.c_int, [ctypes.c_longlong]),
+    "psvo_dense_forward": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, _P, _P, _P, ctypes.c_int, _P, _P]),
+    "psvo_dense_backward": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, ctypes.c_int,
+                                           _P, _P, _P, ctypes.c_int, _P]),
     "psvo_bilstm_forward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 8 + [_P]),
     "psvo_bilstm_backward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 10 + [_P]),
     "psvo_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,

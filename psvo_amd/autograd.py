@@ -304,6 +304,25 @@ class RowsMLPFunction(torch.autograd.Function):
         return (None, dX) + tuple(ops.split_mlp_grad(g, Din, H, Dout))
 
 
+class DenseFunction(torch.autograd.Function):
+    """psvo_dense_forward / psvo_dense_backward: one Dense layer (keras layout, optional relu) over (R, Din) rows on
+    v_mfma_f32_16x16x4_f32.  apply(X, W, b, relu) -> (R, Dout)."""
+
+    @staticmethod
+    def forward(ctx, X, W, b, relu):
+        X, W, b = _cf(X), _cf(W), _cf(b)
+        Y = ops.dense_forward(X, W, b, relu)
+        ctx.relu, ctx.need_dX = bool(relu), ctx.needs_input_grad[0]
+        ctx.saved = (X, W, Y if relu else None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W, Y = ctx.saved
+        dX, dW, db = ops.dense_backward(X, Y, _cg(dY).float(), W, ctx.relu, need_dX=ctx.need_dX)
+        return dX, dW, db, None
+
+
 class ElboBsimFunction(torch.autograd.Function):
     """psvo_elbo_bsim_mean / psvo_elbo_bsim_mean_backward: mean_b [logsumexp_n score - log N] (PSVO.py:52-67)
     as one launch each way instead of torch's logsumexp/mean chain between the two bsim kernels."""

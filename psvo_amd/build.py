@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpsvo_hip.so")
 SOURCES = ["api.hip", "filter_fwd.hip", "bsim_fwd.hip", "lstm.hip", "filter_bwd.hip", "mlp_grad.hip", "bsim_bwd.hip", "bsim_bwd_dx2.hip", "bsim_bwd_dx3.hip", "bsim_bwd_dx4.hip", "bsim_bwd2_dx2.hip", "bsim_bwd2_dx3.hip", "bsim_bwd2_dx4.hip",
-           "lstm_bwd.hip", "adam.hip", "psvowr_fwd.hip", "psvowr_bwd.hip", "rows_mlp.hip"]
+           "lstm_bwd.hip", "adam.hip", "psvowr_fwd.hip", "psvowr_bwd.hip", "rows_mlp.hip", "dense.hip"]
 HEADERS = ["common.h", "bsim_bwd_impl.h", "bsim_bwd2_impl.h", os.path.join("..", "..", "include", "psvo_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize"]
 

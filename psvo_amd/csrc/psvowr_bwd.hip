@@ -125,9 +125,9 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
     float* wqi = wg + MG::kSize;
     float* tile = wqi + MQ::kSize;              // [2][NP][PS]
     float* jacc = tile + 2 * NP * PS;           // [nw][NA][NP] wave-private d F' / d W^ sums of the step
-    float* dxs = jacc + nw * NA * NP;           // [DX][Nc] d loss / d (selected sub-particle) of the own chains
-    float* red = dxs + DX * Nc;                 // 64
-    int* xpar = reinterpret_cast<int*>(red + 64);   // [N] ancestor of chain k at this step, relative to c0
+    constexpr int kXq = (DX <= 3) ? 4 : 8;      // floats per child in xq: d loss / d bwXanc_t[k] (DX), ..., parent (last)
+    float* red = jacc + nw * NA * NP;           // 64
+    float* xq = red + 64;                       // [N][kXq] polled gradients of the children gathered from our chains
 
     MQ::load(wf, a.f, tid, NTB);
     MG::load(wg, a.g, tid, NTB);
@@ -272,10 +272,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
         WbIn<DX> in0;
         load_in(tb, 0, last, first, in0);
 
-        for (int i = tid; i < DX * Nc; i += NTB) dxs[i] = 0.f;
         for (int i = tid; i < nw * NA * NP; i += NTB) jacc[i] = 0.f;
-        if (t >= 1)
-            for (int k = tid; k < N; k += NTB) xpar[k] = a.anc[tb * N + k] - c0;   // parents of this step's gathers
         __syncthreads();
 
         float* ja = jacc + wave * NA * NP;
@@ -467,26 +464,29 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
                 if (t >= 1) {
                     const unsigned long long* const slot = a.ring + ((size_t)t * B + b) * N * kWbWords;
                     const unsigned tag = (unsigned)(t + 1);
-                    // Scatter-add of the published gradients into the parents this workgroup owns, in a FIXED order (LDS float
-                    // atomics would make the gradients differ from launch to launch): S lanes per (parent, d) walk the
-                    // children k = s, s + S, ... in ascending order, poll the word of every child whose parent is theirs
-                    // (bounded spin; xpar[] = this step's ancestors relative to c0, staged at the top of the step), and are
-                    // folded by a fixed xor tree.  Every word is polled by exactly one lane.
-                    const int pairs = DX * Nc;
-                    const int S = (16 * pairs <= NTB) ? 16 : (8 * pairs <= NTB) ? 8 : (4 * pairs <= NTB) ? 4
-                                                      : (2 * pairs <= NTB) ? 2 : 1;
-                    const int pr = tid / S, sl = tid - pr * S;
-                    float acc_s = 0.f;
-                    if (pr < pairs) {
-                        const int d = pr / Nc, pl = pr - d * Nc;
-                        for (int k = sl; k < N; k += S) {
-                            if (xpar[k] != pl) continue;
-                            const unsigned long long* const w = slot + (size_t)k * kWbWords + d;
+                    // Poll, one lane per child chain k whose parent this workgroup owns (all polls in flight together:
+                    // one round trip), and stage {d loss / d bwXanc_t[k] (DX), parent} in LDS.  The scatter-add into the
+                    // parents is done by the CONSUMERS below in a fixed order -- no LDS float atomics, whose order would
+                    // make the gradients differ from launch to launch.
+                    for (int k = tid; k < N; k += NTB) {
+                        const int p = a.anc[tb * N + k] - c0;
+                        float val[DX];
+#pragma unroll
+                        for (int d = 0; d < DX; ++d) val[d] = 0.f;
+                        if (p >= 0 && p < c1 - c0) {   // (its owner wrote the words during step t-1; bounded spin)
+                            const unsigned long long* const w = slot + (size_t)k * kWbWords;
                             unsigned spins = 0;
                             for (;;) {
-                                const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if ((unsigned)(v >> 32) == tag) {
-                                    acc_s += __uint_as_float((unsigned)v);
+                                unsigned long long v[DX];
+                                bool ok = true;
+#pragma unroll
+                                for (int d = 0; d < DX; ++d) {
+                                    v[d] = __hip_atomic_load(w + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    ok = ok && (unsigned)(v[d] >> 32) == tag;
+                                }
+                                if (ok) {
+#pragma unroll
+                                    for (int d = 0; d < DX; ++d) val[d] = __uint_as_float((unsigned)v[d]);
                                     break;
                                 }
                                 __builtin_amdgcn_s_sleep(1);
@@ -498,18 +498,30 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
                                 }
                             }
                         }
+                        float* q8 = xq + k * kXq;
+#pragma unroll
+                        for (int d = 0; d < DX; ++d) q8[d] = val[d];
+                        q8[kXq - 1] = __int_as_float((p >= 0 && p < c1 - c0) ? p : -1);
                     }
-                    if (S >= 2) acc_s += xor_lane<1>(acc_s);
-                    if (S >= 4) acc_s += xor_lane<2>(acc_s);
-                    if (S >= 8) acc_s += xor_lane<4>(acc_s);
-                    if (S >= 16) acc_s += xor_lane<8>(acc_s);
-                    if (pr < pairs && sl == 0) dxs[pr] = acc_s;
                 }
                 __syncthreads();
             }
             SEC(5);   // exchange poll + barrier
+            if (t >= 1) {
+                // d loss / d (selected sub-particle of chain nl) = sum over the children k gathered from it, in a fixed
+                // order: lane m of the chain takes k = m, m + M, ..., the M lanes are folded by a fixed xor tree
+                float gs[DX];
 #pragma unroll
-            for (int d = 0; d < DX; ++d) dxt[d] += issel * dxs[d * Nc + nl];
+                for (int d = 0; d < DX; ++d) gs[d] = 0.f;
+                for (int k = m; k < N; k += M) {
+                    const float* q8 = xq + k * kXq;
+                    const bool mine = __float_as_int(q8[kXq - 1]) == nl;
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) gs[d] += mine ? q8[d] : 0.f;
+                }
+#pragma unroll
+                for (int d = 0; d < DX; ++d) dxt[d] += issel * group_sum<M>(gs[d]);
+            }
 
             // ---- reduce over the chain's M sub-particles --------------------------------------------------------
             float dmu[DX], sce[DX], dxp[DX], dim[DX];
@@ -597,7 +609,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
             if (tid == 0) a.dlse_part[tb * K + kb] = 0.f;
         }
         if (staging && one_entry) stage_store(nxt);
-        __syncthreads();   // (dxs / jacc are cleared at the top of the next step)
+        __syncthreads();   // (jacc is cleared at the top of the next step)
         SEC(7);   // per-workgroup partials of d Fm / d logW / d lse, barrier
     }
 
@@ -665,7 +677,7 @@ static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stre
     if (NTB > 512) NTB = 512;
     const int nw = NTB / 64;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + (size_t)nw * (DX + 1) * NP +
-                                        (size_t)DX * Nc + 64 + (size_t)a.N);
+                                        64 + (size_t)((DX <= 3) ? 4 : 8) * a.N);
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
     // tags of an earlier launch must not be mistaken for this one's: clear the ring and the error flag

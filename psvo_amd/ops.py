@@ -334,6 +334,39 @@ def rows_mlp_backward(X, dOut, w, need_dX=True, grad=None):
     return dX, grad
 
 
+def dense_forward(X, W, b, relu):
+    """psvo_dense_forward: X (R, Din) -> act(X W + b) (R, Dout) on the f32 matrix instruction."""
+    lib = _lib.load()
+    R, Din = X.shape
+    Dout = W.shape[1]
+    _chk(X, (R, Din), "X"); _chk(W, (Din, Dout), "W"); _chk(b, (Dout,), "b")
+    Y = _empty(R, Dout, device=X.device)
+    _mark("psvo_dense_forward", 0)
+    st = lib.psvo_dense_forward(R, Din, Dout, _ptr(X), _ptr(W), _ptr(b), int(relu), _ptr(Y), _stream())
+    _mark("psvo_dense_forward", 1)
+    _lib.check(st, "psvo_dense_forward")
+    return Y
+
+
+def dense_backward(X, Y, dY, W, relu, need_dX=True):
+    """psvo_dense_backward -> (dX (R, Din) or None, dW (Din, Dout), db (Dout))."""
+    lib = _lib.load()
+    R, Din = X.shape
+    Dout = W.shape[1]
+    _chk(X, (R, Din), "X"); _chk(dY, (R, Dout), "dY"); _chk(W, (Din, Dout), "W")
+    if relu:
+        _chk(Y, (R, Dout), "Y")
+    dX = _empty(R, Din, device=X.device) if need_dX else None
+    partial = _empty(lib.psvo_dense_wgrad_slices(R), (Din + 1) * Dout, device=X.device)
+    grad = _empty((Din + 1) * Dout, device=X.device)
+    _mark("psvo_dense_backward", 0)
+    st = lib.psvo_dense_backward(R, Din, Dout, _ptr(X), _ptr(Y) if relu else None, _ptr(dY), _ptr(W), int(relu), _ptr(dX),
+                                 _ptr(partial), _ptr(grad), 0, _stream())
+    _mark("psvo_dense_backward", 1)
+    _lib.check(st, "psvo_dense_backward")
+    return dX, grad[:Din * Dout].view(Din, Dout), grad[Din * Dout:]
+
+
 def split_mlp_grad(g, Din, H, Dout):
     """flat [dW1|db1|dW2|db2] -> (dW1 (Din,H), db1 (H), dW2 (H,Dout), db2 (Dout)) views."""
     a = Din * H

@@ -39,13 +39,14 @@ class MLP_transformation(nn.Module):
         self.mu_kernel = nn.Parameter(_he_normal_(torch.empty(d, Dout)))   # mu_layer: Dense(linear)
         self.mu_bias = nn.Parameter(torch.zeros(Dout))
 
-    # limits of the native row kernels (psvo_rows_mlp_*, csrc/rows_mlp.hip)
+    # limits of the fused one-hidden-layer row kernels (psvo_rows_mlp_*, csrc/rows_mlp.hip); anything else that is a plain
+    # chain of Dense layers goes layer by layer through psvo_dense_* (csrc/dense.hip, f32 MFMA)
     _NATIVE_H, _NATIVE_DIN, _NATIVE_DOUT = (16, 32, 64), 128, 4
 
     def _native_refusal(self, Input):
-        """why psvo_rows_mlp_* cannot evaluate this MLP on `Input` (None if it can)"""
+        """why the fused psvo_rows_mlp_* pair cannot evaluate this MLP on `Input` (None if it can)"""
         if len(self.Dhs) != 1:
-            return "%d hidden layers %s (the native kernels take exactly one)" % (len(self.Dhs), self.Dhs)
+            return "%d hidden layers %s (the fused kernels take exactly one)" % (len(self.Dhs), self.Dhs)
         if self.use_residual:
             return "use_residual=True"
         if self.Dhs[0] not in self._NATIVE_H:
@@ -61,18 +62,27 @@ class MLP_transformation(nn.Module):
     def transform(self, Input):
         """reference MLP.py:48-68; returns (mu, None).
 
-        Tensors in HBM go through the native row kernels (one launch forward, one backward) or not at all: a shape the
-        kernels do not cover raises ValueError -- there is no PyTorch-op fallback on the GPU.  CPU tensors take the plain
+        Tensors in HBM go through native kernels only: the fused one-hidden-layer pair psvo_rows_mlp_* where it applies
+        (one launch forward, one backward), otherwise one psvo_dense_* launch per Dense layer (any number of hidden layers,
+        widths up to 4096) -- there is no PyTorch-op fallback on the GPU.  CPU tensors take the plain
         matmul form below; that is the host-side mirror the CPU tests of the host logic (encoder wiring, k-step
         prediction, R-square) run on a machine without a GPU, never part of the GPU path."""
         if Input.is_cuda:
-            why = self._native_refusal(Input)
-            if why is not None:
-                raise ValueError("%s: no native kernel for this MLP on the GPU: %s (no PyTorch fallback exists; "
-                                 "limits: one hidden layer of %s units, <= %d inputs, <= %d outputs)"
-                                 % (self.name, why, self._NATIVE_H, self._NATIVE_DIN, self._NATIVE_DOUT))
-            from ..autograd import RowsMLPFunction
+            if Input.dtype != torch.float32:
+                raise ValueError("%s: the native kernels compute in float32, got %s (no PyTorch fallback exists)"
+                                 % (self.name, Input.dtype))
             X = Input.reshape(-1, Input.shape[-1])
+            if self._native_refusal(Input) is not None:
+                # several hidden layers / wide layers: one native Dense launch per layer (f32 MFMA GEMM)
+                from ..autograd import DenseFunction
+                hidden = X
+                for W, b in zip(self.kernels, self.biases):
+                    hidden = DenseFunction.apply(hidden, W, b, True)
+                mu = DenseFunction.apply(hidden, self.mu_kernel, self.mu_bias, False)
+                if self.use_residual:
+                    mu = mu + X
+                return mu.reshape(Input.shape[:-1] + (mu.shape[-1],)), None
+            from ..autograd import RowsMLPFunction
             mu = RowsMLPFunction.apply(self.__dict__.get("_flat_grad"), X, self.kernels[0], self.biases[0],
                                        self.mu_kernel, self.mu_bias)
             return mu.reshape(Input.shape[:-1] + (mu.shape[-1],)), None
