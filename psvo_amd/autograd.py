@@ -122,17 +122,35 @@ class FilterFunction(torch.autograd.Function):
                 # the bsim weight gradients (event below) and, outside the default wiring, the hoisted f.mean(mu_0) on
                 # the main stream -- only then wait for everything the main stream issued before this node (with the
                 # second side stream in use there is no such writer, and waiting would serialise behind the encoder BPTT)
+                kernel_done.record(side)                 # the reverse kernel's own outputs (d mu2, d m0, scale sums) exist
                 if ov.side2 is None:
                     side.wait_event(entered)
                 if ov.bsim_wgrad_done is not None:       # (recorded on the second side stream when used)
                     side.wait_event(ov.bsim_wgrad_done)
+            kernel_done = torch.cuda.Event()
             with ops.launch_on(side):
                 r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
                                         obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
-                                        gbufs=ctx.gbufs, before_wgrad=before_wgrad)
-            main.wait_stream(side)
-            if ov.bsim_wgrad_done is not None:
-                main.wait_event(ov.bsim_wgrad_done)
+                                        gbufs=ctx.gbufs, before_wgrad=before_wgrad,
+                                        wgrad_stream2=ov.side2 if ctx.gbufs is not None else None, kernel_done=kernel_done)
+            if ctx.gbufs is not None:
+                # the weight gradients accumulate straight into the flat gradient buffer: nothing downstream on the main
+                # stream reads them, so the main stream (hoisted q2 / q0 backward, scale gradients) continues as soon as
+                # the reverse KERNEL is done and the weight-gradient launches overlap it; the streams are joined once, when
+                # the backward pass ends (before the gradient all-reduce / Adam)
+                main.wait_event(kernel_done)
+
+                side2 = ov.side2
+
+                def join():
+                    torch.cuda.current_stream().wait_stream(side)
+                    if side2 is not None:
+                        torch.cuda.current_stream().wait_stream(side2)
+                torch.autograd.variable.Variable._execution_engine.queue_callback(join)
+            else:
+                main.wait_stream(side)
+                if ov.bsim_wgrad_done is not None:
+                    main.wait_event(ov.bsim_wgrad_done)
             _used_on(main, r.values())
         else:
             r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
