@@ -322,11 +322,14 @@ def main():
             e.record(torch.cuda.current_stream())
             marks.append(("step", 0, e))
 
+    from psvo_amd import autograd as _ag
+
     def train_step():
         mark_step()
         flat.zero_grad()
         z, _ = smc.get_log_ZSMC(obs, hidden)
-        z.backward()
+        with _ag.deferred_join():
+            z.backward()
         dp.all_reduce_sum_(flat.grad)
         opt.step(lr, world_size=world)
         return z
@@ -345,7 +348,8 @@ def main():
     def local_step():
         flat.zero_grad()
         z, _ = smc.get_log_ZSMC(obs, hidden)
-        z.backward()
+        with _ag.deferred_join():
+            z.backward()
         return z.detach()
 
     def update():

@@ -22,6 +22,33 @@ from . import ops
 # ---------------------------------------------------------------------------------------------
 _SIDE = {}
 OVERLAP = True
+# Opt-in: let the main stream run ahead of the filter's weight-gradient launches at the end of the reverse pass.  Whoever sets
+# this MUST call join_deferred() after backward() and before reading or reducing the gradients (trainer.train_step and
+# bench.py do); left False, FilterFunction.backward joins the streams itself and gradients are safe to read on return.
+DEFER_JOIN = False
+_PENDING_JOIN = []
+
+
+def join_deferred():
+    """order the current stream after the side-stream launches that backward() left running (no-op if none)"""
+    cur = torch.cuda.current_stream() if _PENDING_JOIN else None
+    while _PENDING_JOIN:
+        cur.wait_stream(_PENDING_JOIN.pop())
+
+
+class deferred_join(object):
+    """with autograd.deferred_join(): loss.backward()   -- sets DEFER_JOIN for the block and joins on exit"""
+
+    def __enter__(self):
+        global DEFER_JOIN
+        self.prev, DEFER_JOIN = DEFER_JOIN, True
+        return self
+
+    def __exit__(self, *exc):
+        global DEFER_JOIN
+        DEFER_JOIN = self.prev
+        join_deferred()
+        return False
 
 
 class Overlap(object):
@@ -132,21 +159,15 @@ class FilterFunction(torch.autograd.Function):
                 r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
                                         obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
                                         gbufs=ctx.gbufs, before_wgrad=before_wgrad,
-                                        wgrad_stream2=ov.side2 if ctx.gbufs is not None else None, kernel_done=kernel_done)
-            if ctx.gbufs is not None:
+                                        wgrad_stream2=ov.side2 if (ctx.gbufs is not None and DEFER_JOIN) else None,
+                                        kernel_done=kernel_done)
+            if ctx.gbufs is not None and DEFER_JOIN:
                 # the weight gradients accumulate straight into the flat gradient buffer: nothing downstream on the main
                 # stream reads them, so the main stream (hoisted q2 / q0 backward, scale gradients) continues as soon as
-                # the reverse KERNEL is done and the weight-gradient launches overlap it; the streams are joined once, when
-                # the backward pass ends (before the gradient all-reduce / Adam)
+                # the reverse KERNEL is done and the weight-gradient launches overlap it; the caller joins the streams once,
+                # after backward() and before it touches the gradients (autograd.join_deferred(): trainer, bench)
                 main.wait_event(kernel_done)
-
-                side2 = ov.side2
-
-                def join():
-                    torch.cuda.current_stream().wait_stream(side)
-                    if side2 is not None:
-                        torch.cuda.current_stream().wait_stream(side2)
-                torch.autograd.variable.Variable._execution_engine.queue_callback(join)
+                _PENDING_JOIN.extend(st for st in (side, ov.side2) if st is not None)
             else:
                 main.wait_stream(side)
                 if ov.bsim_wgrad_done is not None:

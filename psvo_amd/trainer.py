@@ -19,7 +19,7 @@ import time
 import numpy as np
 import torch
 
-from . import dp
+from . import autograd, dp
 from .optim import FlatParams, TFAdam
 
 
@@ -111,7 +111,8 @@ class trainer:
         if log_ZSMC is None:
             self.flat.zero_grad()
             log_ZSMC, _ = self.SMC.get_log_ZSMC(obs, hidden)
-            log_ZSMC.backward()
+            with autograd.deferred_join():
+                log_ZSMC.backward()
         dp.all_reduce_sum_(self.flat.grad)
         self.optimizer.step(lr, world_size=dp.world_size())
         return log_ZSMC.detach()
@@ -133,7 +134,8 @@ class trainer:
                 def local_step():
                     self.flat.zero_grad()
                     z, _ = self.SMC.get_log_ZSMC(s_obs, s_hidden)
-                    z.backward()
+                    with autograd.deferred_join():
+                        z.backward()
                     return z.detach()
                 g = (GraphedStep(local_step, generators=[self.SMC.generator]), s_obs, s_hidden)
             except Exception as exc:     # fall back to eager issue for this shape from now on
