@@ -158,14 +158,14 @@ class FilterFunction(torch.autograd.Function):
             with ops.launch_on(side):
                 r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
                                         obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
-                                        gbufs=ctx.gbufs, before_wgrad=before_wgrad,
-                                        wgrad_stream2=ov.side2 if (ctx.gbufs is not None and DEFER_JOIN) else None,
-                                        kernel_done=kernel_done)
+                                        gbufs=ctx.gbufs, before_wgrad=before_wgrad)
             if ctx.gbufs is not None and DEFER_JOIN:
                 # the weight gradients accumulate straight into the flat gradient buffer: nothing downstream on the main
                 # stream reads them, so the main stream (hoisted q2 / q0 backward, scale gradients) continues as soon as
                 # the reverse KERNEL is done and the weight-gradient launches overlap it; the caller joins the streams once,
-                # after backward() and before it touches the gradients (autograd.join_deferred(): trainer, bench)
+                # after backward() and before it touches the gradients (autograd.join_deferred(): trainer, bench).
+                # (Also moving MLP_g's weight gradient to the second side stream, beside MLP_q1's, crashed
+                #  hipStreamEndCapture on ROCm 7.2 and was dropped: ~20 us.)
                 main.wait_event(kernel_done)
                 _PENDING_JOIN.extend(st for st in (side, ov.side2) if st is not None)
             else:

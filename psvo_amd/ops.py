@@ -374,7 +374,7 @@ def split_mlp_grad(g, Din, H, Dout):
 
 
 def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs, eps, filt,
-                    dlse=None, dFm=None, dlogW=None, gbufs=None, before_wgrad=None, wgrad_stream2=None, kernel_done=None):
+                    dlse=None, dFm=None, dlogW=None, gbufs=None, before_wgrad=None):
     """psvo_filter_backward + psvo_mlp_wgrad.  `filt` = forward outputs.  dFm (T,B,Dx,N) / dlogW (T,B,N)
     are upstream gradients (or None).  Returns a dict of gradients."""
     lib = _lib.load()
@@ -408,14 +408,7 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
     gb = gbufs or (None, None, None)
     out["gq1"] = mlp_wgrad(filt["X"], out["dP"], q1, Dx, H, Dx, grad=gb[0])
     out["gf"] = None if desc.bootstrap else mlp_wgrad(filt["X"], out["dF"], f, Dx, H, Dx, grad=gb[1])
-    if wgrad_stream2 is not None and kernel_done is not None and gbufs is not None:
-        # MLP_g's weight gradient on a second stream, beside MLP_q1's (different slices of the flat gradient buffer; the
-        # stream is the one the backward simulation's weight gradients ran on, so it is ordered after their write of g's)
-        wgrad_stream2.wait_event(kernel_done)
-        with launch_on(wgrad_stream2):
-            out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy, grad=gb[2])
-    else:
-        out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy, grad=gb[2])
+    out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy, grad=gb[2])
     return out
 
 
