@@ -298,12 +298,9 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
 // latency chain; with lane = particle the two dependent MLP evaluations were > 40 % of it.  Here particle
 // n owns the quad of lanes 4n..4n+3: lane p evaluates hidden units [p*H/4, (p+1)*H/4) of every MLP (its
 // slice of the weights is loop-invariant and stays in registers) and the outputs are summed over the quad
-// with two DPP adds.  Everything else is computed redundantly in the four lanes.  A step has ONE workgroup barrier
-// (round 1 had three): every wave stages its 16 particles' weight sums relative to its OWN maximum and its (max, total)
-// pair; after the barrier every lane combines the <= 16 pairs in the lanes of a DPP row (log-sum-exp, per-block scale
-// and offset) and runs the two-round 16-ary multinomial search against global CDF entries formed on the fly,
-// fma(local, scale_block, offset_block) -- bit for bit the values a stored global CDF held -- so no second barrier is
-// needed to publish one; the staging buffers alternate with the step parity, so none is needed at the end of a step.
+// with two DPP adds.  Everything else is computed redundantly in the four lanes; the multinomial search is a
+// two-round 16-ary search in which the quad reads 16 CDF pivots / 16 CDF entries as four float4 per round.
+// The per-sequence log-sum-exp and CDF use per-wave maxima and ONE barrier.
 // ---------------------------------------------------------------------------------------------
 template <int DX, int DY, int H, int MAXT>
 __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a) {
@@ -325,18 +322,18 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
     float* wq1 = smem;
     float* wf = wq1 + MQ::kSize;
     float* wg = wf + MQ::kSize;
-    // per-step staging, DOUBLE-BUFFERED by step parity (so that no barrier is needed at the end of a step: a wave that
-    // runs ahead into step t + 1 writes the other buffer, and it can only reach step t + 2 through step t + 1's barrier,
-    // which every wave passes after it has finished reading step t's buffer):
-    //   cdf [NPT] wave-LOCAL inclusive weight sums (relative to the wave's own maximum) | red [2][16] per-wave (max, sum)
-    //   | sx, sp, sf [DX][NPT] staged X_t, MLP_q1(X_t), MLP_f(X_t) (sf unused when bootstrap)
-    float* const stg = wg + MG::kSize;
-    const int kStage = NPT + 32 + 3 * DX * NPT;
+    float* cdf = wg + MG::kSize;   // [NPT]
+    float* piv = cdf + NPT;        // [16] cdf[16 i + 15], +inf beyond the last block
+    float* sx = piv + 16;          // [DX][NPT] staged X_t
+    float* sp = sx + DX * NPT;     // [DX][NPT] staged MLP_q1(X_t)
+    float* sf = sp + DX * NPT;     // [DX][NPT] staged MLP_f(X_t) (unused when bootstrap)
+    float* red = sf + DX * NPT;    // [2][16] per-wave (max, sum)
 
     MQ::load(wq1, a.q1, tid, NT);
     if (!a.bootstrap) MQ::load(wf, a.f, tid, NT);
     MG::load(wg, a.g, tid, NT);
     const float* wfm = a.bootstrap ? wq1 : wf;
+    if (tid < 16) piv[tid] = __builtin_huge_valf();
 
     float sq1[DX], sq2[DX], sfv[DX], s0[DX], fs0[DX], isg[DY];
     float lg = -DY * kHalfLog2Pi;
@@ -396,11 +393,6 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         float eps_n[DX], mu2_n[DX], obs_n[DY], u_n = 0.f;
         int idx_n = 0;
         if (t + 1 < T) load_inputs(t + 1, eps_n, mu2_n, obs_n, u_n, idx_n);
-        float* const cdf = stg + (t & 1) * kStage;
-        float* const red = cdf + NPT;
-        float* const sx = red + 32;
-        float* const sp = sx + DX * NPT;
-        float* const sf = sp + DX * NPT;
 
         SEC(1);
         // ---- proposal (SVO.py:186-197), densities: the same in the four lanes of the particle --------
@@ -453,19 +445,17 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         }
 
         SEC(3);   // MLPs, quad sums, weight, history stores
-        // ---- log-sum-exp over particles + CDF: per-wave maxima and wave-local sums, ONE barrier per step ----------------
+        // ---- log-sum-exp over particles + CDF: per-wave maxima, one barrier ------------------------------
         const float wmx = wave_max(lw);
         const float wbase = (wmx == ninf) ? 0.f : wmx;
         const float w = (valid && p == 0) ? exp2_fast((lw - wbase) * kLog2e) : 0.f;
-        const float sc = wave_incl_scan(w, lane);     // wave-local inclusive sum (lane 63: the wave's total)
+        float sc = wave_incl_scan(w, lane);
         if (lane == 63) {
             red[wave] = wmx;
             red[16 + wave] = sc;
         }
-        if (a.resample) {   // stage the local CDF and the pre-resampling particle for the gather (one lane of the quad each)
-            if (p == 0) {
-                cdf[pn] = sc;
-            } else if (p == 1) {
+        if (a.resample) {   // stage the pre-resampling particle for the gather (one lane of the quad per array)
+            if (p == 1) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) sx[d * NPT + pn] = x[d];
             } else if (p == 2) {
@@ -479,8 +469,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         SEC(4);   // wave max / scan, staging writes
         __syncthreads();
         SEC(5);   // barrier
-        // combine the (max, sum) pairs of the <= 16 waves in the lanes of a row: lane i holds wave i (= block i of 16
-        // particles: a wave of four lanes per particle holds exactly 16 of them)
+        // combine the (max, sum) pairs of the <= 16 waves in the lanes of a row: lane i holds wave i
         const int li = lane & 15;
         const float m_i = li < nw ? red[li] : ninf;
         const float s_i = li < nw ? red[16 + li] : 0.f;
@@ -489,35 +478,33 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         const float v_i = s_i * exp2_fast((m_i - gbase) * kLog2e);        // (empty wave: 0 * exp2(-inf) = 0)
         const float pre = group_incl_scan<16>(v_i, li);
         const float total = lane_bcast(pre, nw - 1);
+        const float off = uwave > 0 ? lane_bcast(pre, max(uwave - 1, 0)) : 0.f;   // sum over the waves before this one
+        sc = fmaf(sc, exp2_fast((wbase - gbase) * kLog2e), off);
         const float lse_t = fmaf(kLn2, log2_fast(total), gmx);
         if (tid == 3) a.lse[tb] = lse_t;
 
         SEC(6);   // cross-wave combination
         if (a.resample) {
+            if (p == 0) {
+                cdf[pn] = sc;
+                if ((pn & 15) == 15) piv[pn >> 4] = sc;
+            }
+            __syncthreads();
+            SEC(7);   // cdf store + barrier
             int idx;
             if (a.idx_in) {
                 idx = idx_c;
             } else {
-                // idx = #{k : cdf[k] <= u * total} (SVO.py:266-300 as defined in the oracle) with the global CDF entry of
-                // particle k of block i  cdf[k] = fma(local[k], scale_i, off_i),  scale_i = exp2((wmax_i - gmax) log2 e),
-                // off_i = sum of the scaled totals of the blocks before i -- the values a stored global CDF would hold,
-                // formed here on the fly so that the search needs no second barrier.  Round 1: the 16 block ends
-                // (pivots, in the lanes of the row), round 2: the 16 entries of the block found.
+                // idx = #{k : cdf[k] <= u * total} (SVO.py:266-300 as defined in the oracle), two 16-ary rounds
                 const float target = u_c * total;
-                const float excl = li > 0 ? dpp_mov<0x111, 0xF, 0xF, true>(0.f, pre) : 0.f;   // off_i (row_shr:1)
-                const float mb_i = (m_i == ninf) ? 0.f : m_i;
-                const float scale_i = exp2_fast((mb_i - gbase) * kLog2e);
-                const float piv_i = li < nw ? fmaf(s_i, scale_i, excl) : __builtin_huge_valf();
-                int c1 = 0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) c1 += (lane_bcast(piv_i, i) <= target) ? 1 : 0;
-                const int blk = min(c1, (NPT >> 4) - 1);
-                // scale and offset of the block found: per-lane gather from the row's lanes
-                const int src = (lane & ~15) | blk;
-                const float scale_b = __shfl(scale_i, src), off_b = __shfl(excl, src);
+                const float4 pv = *reinterpret_cast<const float4*>(piv + 4 * p);
+                float c1 = (pv.x <= target ? 1.f : 0.f) + (pv.y <= target ? 1.f : 0.f) +
+                           (pv.z <= target ? 1.f : 0.f) + (pv.w <= target ? 1.f : 0.f);
+                c1 = group_sum<P>(c1);
+                const int blk = min((int)c1, (NPT >> 4) - 1);
                 const float4 cv = *reinterpret_cast<const float4*>(cdf + 16 * blk + 4 * p);
-                float c2 = (fmaf(cv.x, scale_b, off_b) <= target ? 1.f : 0.f) + (fmaf(cv.y, scale_b, off_b) <= target ? 1.f : 0.f) +
-                           (fmaf(cv.z, scale_b, off_b) <= target ? 1.f : 0.f) + (fmaf(cv.w, scale_b, off_b) <= target ? 1.f : 0.f);
+                float c2 = (cv.x <= target ? 1.f : 0.f) + (cv.y <= target ? 1.f : 0.f) +
+                           (cv.z <= target ? 1.f : 0.f) + (cv.w <= target ? 1.f : 0.f);
                 c2 = group_sum<P>(c2);
                 idx = min(16 * blk + (int)c2, N - 1);
             }
@@ -535,7 +522,9 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
                 }
             }
             lnw = neg_logN;
-            SEC(8);   // search, gather, stores  (no barrier: the staging buffers alternate with the step parity)
+            SEC(8);   // search, gather, stores
+            __syncthreads();  // staged arrays / red[] are rewritten next step
+            SEC(9);   // barrier
         } else {
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
@@ -550,6 +539,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
                 }
             }
             lnw = lw - lse_t;
+            __syncthreads();  // red[] reuse
         }
 
 #pragma unroll
@@ -577,7 +567,7 @@ static int launch_filter(const FilterArgs& a, hipStream_t stream) {
         if (a.N <= 128) {
             const int NT4 = (4 * a.N + 63) & ~63;
             const int NPT = NT4 / 4;
-            const size_t lds4 = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (NPT + 32 + 3 * DX * NPT));
+            const size_t lds4 = sizeof(float) * (2 * MQ::kSize + MG::kSize + NPT + 16 + 3 * DX * NPT + 32);
             clear_hip_error();
             hipLaunchKernelGGL((filter_fwd_lpp_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT4), lds4, stream, a);
             return launch_status();
