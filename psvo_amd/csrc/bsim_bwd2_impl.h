@@ -310,7 +310,11 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
         if (t + 1 < T && t >= 1) stage_load(t);
         // the offsets are advanced to step t+1 for the prefetch; this step's stores subtract the stride again
         advance();
-        if (t + 1 < T) load_step(t + 2 == T, false, nxt_in);
+        // Dx <= 2: the next step's inputs are requested here, a whole step ahead.  Dx >= 3: only after the pair phase (the
+        // 3 Dx + 4 registers they land in would be live across it, and the kernel is at its 256-VGPR budget there); the MLP
+        // phase, the chain reductions and the two barriers that follow still cover most of their latency.
+        constexpr bool kLatePrefetch = (DX >= 3);
+        if (!kLatePrefetch && t + 1 < T) load_step(t + 2 == T, false, nxt_in);
         SEC(1);   // issue of the prefetch loads
 
         // ---- recompute the proposal ---------------------------------------------------------------------
@@ -598,6 +602,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
             }
         }
 
+        if (kLatePrefetch && t + 1 < T) load_step(t + 2 == T, false, nxt_in);
         SEC(4);   // hand-back
         // ---- f(x_{t+1} | x~), g(y_t | x~) ------------------------------------------------------------------------
         float dxp_part[DX];

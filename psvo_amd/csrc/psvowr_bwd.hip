@@ -35,18 +35,28 @@ struct WrBwdArgs {
     float *dbmu2_rows, *dminit_rows, *dimean_rows;   // (T,B,Dx,N), (B,Dx,N), (B,Dx,N): per-chain rows
     float* sacc;                                 // (B,K,NACC)
     unsigned long long* ring;                    // exchange ring: d loss / d bwXanc_t of every chain, tagged
+    unsigned* prog;                              // [B][kWbProg] steps consumed by each workgroup of the cluster
     unsigned* err;                               // error flag: a poll timed out
 };
 
-// words a chain publishes per step (d loss / d bwXanc, Dx <= 4) and the exchange workspace: ONE SLOT PER STEP,
-// [T][B][N][kWbWords] tagged 64-bit words {bits(value), tag}, then two 32-bit words whose last one is the error flag.
-// The forward kernel gets away with a two-slot ring because there every workgroup polls all N chains every step, which
-// bounds the run-ahead of any workgroup to one step.  Here a workgroup polls only the chains whose parent it owns; under
-// weight degeneracy most workgroups own no parent for many steps, nothing holds them back, and in a two-slot ring their
-// publication of step t+1 would overwrite words of step t-1 that a slower workgroup has not polled yet.  With a slot per
-// step a word is written once per launch and never overwritten (26 MB at C*; cleared by the launch's memset).
+// words a chain publishes per step (d loss / d bwXanc, Dx <= 4) and the exchange workspace: a ring of D = min(T, 16)
+// slots [D][B][N][kWbWords] of tagged 64-bit words {bits(value), tag = step + 1}, then a progress word per workgroup
+// [B][8] and two 32-bit words whose last one is the error flag.
+// The forward kernel gets away with a two-slot ring and no flow control because there every workgroup polls all N chains
+// every step, which bounds the run-ahead of any workgroup to one step.  Here a workgroup polls only the chains whose parent
+// it owns; under weight degeneracy most workgroups own no parent for many steps, nothing holds them back, and their
+// publication for step t+1 could overwrite words of an earlier step that a slower workgroup has not polled yet.  Hence
+// BACK-PRESSURE: after it has consumed the words of step t a workgroup publishes progress = t + 1; before a workgroup
+// writes into slot (t+1) mod D it makes sure every member of its cluster has consumed that slot's previous occupant (step
+// t+1-D).  The progress words are re-read only when the cached minimum no longer covers the step -- about every D - 2
+// steps in a balanced run -- so the common case costs nothing, and the ring (2 MB at C*) stays in L2 where a slot per
+// step (26 MB, the first fix of round 2) was cold at every step (measured 2.70 ms against 2.39 for the unsafe ring).
 constexpr int kWbWords = 4;
-static inline long long wb_ws_floats(int B, int T, int N) { return 2ll * ((long long)T * B * N * kWbWords) + 2; }
+constexpr int kWbDepth = 16;
+constexpr int kWbProg = 8;       // progress words per sequence (cluster size <= 8)
+static inline int wb_depth(int T) { return T < kWbDepth ? T : kWbDepth; }
+static inline long long wb_ring_floats(int B, int T, int N) { return 2ll * ((long long)wb_depth(T) * B * N * kWbWords); }
+static inline long long wb_ws_floats(int B, int T, int N) { return wb_ring_floats(B, T, N) + (long long)B * kWbProg + 2; }
 
 template <int DX, int DY>
 struct WAcc {   // same slots as BAcc in bsim_bwd_impl.h (shares bsim_bwd_finalize's algebra)
@@ -249,6 +259,8 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
     const bool owner = CH >= 16 || ((lane >> b3) & 1) == 0;
     __syncthreads();
 
+    const int D = T < kWbDepth ? T : kWbDepth;      // ring depth
+    unsigned seen = 0;                              // (lanes < K: cached progress of cluster member `tid`)
     SEC_INIT(psvowr_bwd)
     for (int t = 0; t < T; ++t) {
         const size_t tb = (size_t)t * B + b;
@@ -273,6 +285,22 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
         load_in(tb, 0, last, first, in0);
 
         for (int i = tid; i < nw * NA * NP; i += NTB) jacc[i] = 0.f;
+        // back-pressure: this step publishes into slot (t+1) mod D, whose previous occupant (step t+1-D) every member of the
+        // cluster must have consumed (progress >= t+2-D); `seen` caches the member's progress as of the last look
+        if (t >= D && !last && tid < K) {     // (an occupant exists once t + 1 - D >= 1)
+            const unsigned need = (unsigned)(t + 2 - D);
+            unsigned spins = 0;
+            while (seen < need) {
+                seen = __hip_atomic_load(a.prog + (size_t)b * kWbProg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen >= need) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21) ||
+                    ((spins & 63u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
         __syncthreads();
 
         float* ja = jacc + wave * NA * NP;
@@ -462,7 +490,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
             SEC(4);   // MLP_f / MLP_g forward + input gradients, row stores
             if (r == 0) {
                 if (t >= 1) {
-                    const unsigned long long* const slot = a.ring + ((size_t)t * B + b) * N * kWbWords;
+                    const unsigned long long* const slot = a.ring + ((size_t)(t % D) * B + b) * N * kWbWords;
                     const unsigned tag = (unsigned)(t + 1);
                     // Poll, one lane per child chain k whose parent this workgroup owns (all polls in flight together:
                     // one round trip), and stage {d loss / d bwXanc_t[k] (DX), parent} in LDS.  The scatter-add into the
@@ -505,6 +533,10 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
                     }
                 }
                 __syncthreads();
+                // every lane of this workgroup has read the words of step t: tell the cluster (flow control above)
+                if (tid == 0 && t >= 1)
+                    __hip_atomic_store(a.prog + (size_t)b * kWbProg + kb, (unsigned)(t + 1), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             }
             SEC(5);   // exchange poll + barrier
             if (t >= 1) {
@@ -563,7 +595,7 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
                     if (!last)     // d loss / d bwXanc_{t+1}[n], polled by the parents' owners at step t+1 (tag t+2)
-                        __hip_atomic_store(a.ring + (((size_t)(t + 1) * B + b) * N + n) * kWbWords + d,
+                        __hip_atomic_store(a.ring + (((size_t)((t + 1) % D) * B + b) * N + n) * kWbWords + d,
                                            ((unsigned long long)(unsigned)(t + 2) << 32) |
                                                (unsigned long long)__float_as_uint(dxp[d]),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -768,6 +800,7 @@ extern "C" int psvo_bsimwr_backward(
     a.dbmu2_rows = dbmu2_rows; a.dminit_rows = dminit_rows; a.dimean_rows = dimean_rows; a.sacc = sacc;
     if (reinterpret_cast<uintptr_t>(ws) & 7u) return PSVO_ERR_INVALID;      // 64-bit words
     a.ring = reinterpret_cast<unsigned long long*>(ws);
+    a.prog = reinterpret_cast<unsigned*>(ws + wb_ring_floats(desc->B, desc->T, desc->N));
     a.err = reinterpret_cast<unsigned*>(ws + wb_ws_floats(desc->B, desc->T, desc->N) - 1);
     WrBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig};
     hipStream_t s = static_cast<hipStream_t>(stream);
