@@ -107,8 +107,9 @@ __global__ void dense_fold_kernel(const float* __restrict__ partial, int nz, int
 }
 
 static inline int dense_wgrad_chunks(long long R) {
-    // rows per split-K slice: a multiple of the 16-row slab, about 2048 rows each, at most 256 slices
-    long long nz = (R + 2047) / 2048;
+    // split-K slices of >= 128 rows, at most 256 of them: the product has few output tiles ((Din + 1) x Dout), so the rows
+    // are what fills the chip (R = 6400: 50 slices; 2048-row slices left 8 workgroups walking 100 slabs each: 150 us)
+    long long nz = (R + 127) / 128;
     if (nz > 256) nz = 256;
     if (nz < 1) nz = 1;
     return (int)nz;
