@@ -18,9 +18,10 @@ extern template int bb_dispatch_dy<4>(const BsimBwdArgs&, const BsimBwdOut&, int
 static int g_bsim_bwd_variant = -1;
 
 static int bsim_bwd_variant(int B, int T, int N, int M, int Dx, int Dy) {
-    // measured default (profiles/r02_bsim_bwd_ab.md): v2 wins where its working set fits the 256 VGPRs of two waves per
-    // SIMD (Dx <= 2: C* -8 %, C4 -29 %); at Dx >= 3 it spills to scratch and v1 (one wave per SIMD, 512 VGPRs) is faster
-    int v = g_bsim_bwd_variant < 0 ? (Dx <= 2 ? 1 : 0) : g_bsim_bwd_variant;
+    // measured default (profiles/r02_bsim_bwd_ab.md): v2 wins where its working set fits the 256 VGPRs
+    // of two waves per SIMD -- Dx = 2 (C* -8 %, C4 -29 %) and, with the scalar accumulators in LDS, Dx = 3 (C3 -12 %); at
+    // Dx = 4 it still spills 65 registers to scratch and v1 (one wave per SIMD, 512 VGPRs) is faster
+    int v = g_bsim_bwd_variant < 0 ? (Dx <= 3 ? 1 : 0) : g_bsim_bwd_variant;
     if (v != 0 && !psvo::bsim2_supported(B, T, N, M, Dx, Dy)) v = 0;
     return v;
 }

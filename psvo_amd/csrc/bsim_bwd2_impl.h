@@ -265,9 +265,21 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     }
     __syncthreads();
 
-    float acc[AC::kN];
+    // scalar accumulators of the scale gradients: registers for Dx <= 2; for Dx >= 3 (7 Dx + Dy of them, live across the
+    // pair phase, where the kernel is at its 256-VGPR budget) one wave-private LDS word per lane, updated with ds_add_f32
+    constexpr bool kAccLds = (DX >= 3);
+    float acc[kAccLds ? 1 : AC::kN];
+    float* const accl = red + 16 + wave * AC::kN * 64;       // [nwv][kN][64] (kAccLds only)
+    if constexpr (kAccLds) {
+        for (int i = 0; i < AC::kN; ++i) accl[i * 64 + lane] = 0.f;
+    } else {
 #pragma unroll
-    for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
+        for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
+    }
+    auto acc_add = [&](int k, float v) {
+        if constexpr (kAccLds) atomicAdd(&accl[k * 64 + lane], v);
+        else acc[k] += v;
+    };
     float dX[DX];  // d loss / d bwX_t of this chain (all lanes of the chain hold the same value)
 #pragma unroll
     for (int d = 0; d < DX; ++d) dX[d] = 0.f;
@@ -586,7 +598,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
                     dxt[d] -= dlam * uv[d] * isfk[d];
-                    acc[AC::kSf + d] += dlam * (uv[DX + d] * ikap2 - 1.f) * isf[d];
+                    acc_add(AC::kSf + d, dlam * (uv[DX + d] * ikap2 - 1.f) * isf[d]);
                 }
             }
         } else {
@@ -597,7 +609,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                 const float tz = dphi * z * i_isig[d];
                 if (h0) {
                     dxt[d] -= tz;
-                    acc[AC::kSiota + d] += dphi * (z * z - 1.f) * i_isig[d];
+                    acc_add(AC::kSiota + d, dphi * (z * z - 1.f) * i_isig[d]);
                 }
             }
         }
@@ -623,7 +635,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                     dFo[d] = dphi * z * isf[d];
                     if (h0) {
                         dxp_part[d] = -dFo[d];
-                        acc[AC::kSf + d] += dphi * (z * z - 1.f) * isf[d];
+                        acc_add(AC::kSf + d, dphi * (z * z - 1.f) * isf[d]);
                     }
                 }
                 MQ::template bwd_input_part<PART>(wf, part, x, dFo, dxt);
@@ -645,7 +657,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                 if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
                 const float z = (y[k] - gm[k]) * isg[k];
                 dGo[k] = dphi * z * isg[k] * dmean;
-                if (h0) acc[AC::kSg + k] += dphi * (z * z - 1.f) * isg[k];
+                if (h0) acc_add(AC::kSg + k, dphi * (z * z - 1.f) * isg[k]);
                 if (srow) stf(PSVO_ARG(BsimBwdArgs, dGt), o_knm[k] - s_knm, dGo[k]);
             }
             MG::template bwd_input_part<PART>(wg, part, x, dGo, dxt);
@@ -671,10 +683,10 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                 outv[d] = dmu[d] * pc[d] * pi2[d];
                 if (lead) {
                     stf(PSVO_ARG(BsimBwdArgs, dmu1), o_dn[d] - s_dn, dmu1[d]);
-                    acc[AC::kSc + d] += sce[d] + aw * pic[d];   // -sum_m dq_m / c = a / c
-                    acc[AC::kSmm1 + d] += dmu[d] * mu1[d];
-                    acc[AC::kSmb + d] += dmu[d] * bm[d];
-                    acc[AC::kSmm + d] += dmu[d] * mu[d];
+                    acc_add(AC::kSc + d, sce[d] + aw * pic[d]);   // -sum_m dq_m / c = a / c
+                    acc_add(AC::kSmm1 + d, dmu[d] * mu1[d]);
+                    acc_add(AC::kSmb + d, dmu[d] * bm[d]);
+                    acc_add(AC::kSmm + d, dmu[d] * mu[d]);
                 }
             }
             // MLP_q1inv's input is the same in all G lanes of the chain: spread its hidden units over kQS of them
@@ -693,7 +705,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                 outv[d] = dmu[d];
                 if (lead) {
                     stf(PSVO_ARG(BsimBwdArgs, dmu1), o_dn[d] - s_dn, 0.f);
-                    acc[AC::kSinit + d] += sce[d] + aw * is_init[d];
+                    acc_add(AC::kSinit + d, sce[d] + aw * is_init[d]);
                 }
             }
         }
@@ -745,8 +757,12 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     // ---- scalar accumulators: reduce over the workgroup ---------------------------------------------------------------
     for (int i = 0; i < AC::kN; ++i) {
         float v = 0.f;
+        if constexpr (kAccLds) {
+            v = accl[i * 64 + lane];
+        } else {
 #pragma unroll
-        for (int k = 0; k < AC::kN; ++k) v = (k == i) ? acc[k] : v;
+            for (int k = 0; k < AC::kN; ++k) v = (k == i) ? acc[k] : v;
+        }
         v = wave_sum(v);
         if (lane == 0) red[wave] = v;
         __syncthreads();
@@ -782,7 +798,7 @@ static int launch_bsim_bwd2(const BsimBwdArgs& a, const BsimBwdOut& o, int jm, h
     bsim2_geometry(a.N, M, cpb, nblk);
     const int NP = ((a.N + 127) / 128) * 128;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + 4 * (size_t)(DX + 1) * NP +
-                                        4 * (DX + 2) * 32 + 4 * 32 * UVS + 16);
+                                        4 * (DX + 2) * 32 + 4 * 32 * UVS + 16 + (DX >= 3 ? 4 * (7 * DX + DY) * 64 : 0));
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
     if (jm == 2 && DX == 2) {
