@@ -263,7 +263,7 @@ def main():
     ap.add_argument("--cpu-sample-T", type=int, default=40)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--bsim-bwd-variant", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
+    ap.add_argument("--bsim-bwd-variant", type=int, default=-1, choices=[-1, 0, 1, 2, 3, 4],
                     help="A/B switch of the reverse backward-simulation kernel (psvo_set_tuning, include/psvo_hip.h): "
                          "0 = v1 butterflies, 1 = v2 VALU, 2 = v2 with the per-j sums on f32 MFMA, 3 = v2 with the pair exponents on f32 "
                          "MFMA, -1 = library default")

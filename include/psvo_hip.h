@@ -79,7 +79,8 @@ const char* psvo_status_string(int status);
  *   PSVO_TUNE_BSIM_BWD: which reverse backward-simulation kernel psvo_bsim_backward launches.
  *     -1 default (measured best), 0 = lane = (chain, half, m) with per-j butterflies, 1 = "j on lanes" layout with the per-j
  *     sums on the VALU, 2 = the same with the per-j sums on v_mfma_f32_16x16x4_f32, 3 = the same as 1 with the pair exponents
- *     on v_mfma_f32_16x16x4_f32 (Dx = 2; otherwise as 1).  It changes psvo_bsim_blocks():
+ *     on v_mfma_f32_16x16x4_f32 (Dx = 2; otherwise as 1), 4 = the same as 3 on v_mfma_f32_16x16x32_bf16 with every f32
+ *     operand split into three bf16 pieces (Dx = 2; otherwise as 1).  It changes psvo_bsim_blocks():
  *     set it before sizing workspaces. */
 #define PSVO_TUNE_BSIM_BWD 1
 int psvo_set_tuning(int key, int value);          /* PSVO_OK or PSVO_ERR_INVALID */

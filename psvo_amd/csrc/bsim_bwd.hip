@@ -14,7 +14,8 @@ extern template int bb_dispatch_dy<4>(const BsimBwdArgs&, const BsimBwdOut&, int
 // Which reverse kernel psvo_bsim_backward launches (psvo_set_tuning(PSVO_TUNE_BSIM_BWD, v)):
 //   0 = v1 (lane = (chain, half, m), per-j sums by butterfly),  1 = v2 VALU (bsim_bwd2_impl.h: j on lanes, per-j sums in
 //   registers + swap-add),  2 = v2 with the per-j sums on v_mfma_f32_16x16x4_f32,  3 = v2 with the pair exponents on
-//   v_mfma_f32_16x16x4_f32 (Dx = 2; other Dx run as 1),  -1 = the measured default.  The workspace geometry (psvo_bsim_blocks) follows the choice, so set it before sizing buffers.
+//   v_mfma_f32_16x16x4_f32 (Dx = 2; other Dx run as 1),  4 = v2 with the pair exponents on v_mfma_f32_16x16x32_bf16, operands
+//   split into three bf16 pieces (Dx = 2; other Dx run as 1),  -1 = the measured default.  The workspace geometry (psvo_bsim_blocks) follows the choice, so set it before sizing buffers.
 static int g_bsim_bwd_variant = -1;
 
 static int bsim_bwd_variant(int B, int T, int N, int M, int Dx, int Dy) {
@@ -27,7 +28,7 @@ static int bsim_bwd_variant(int B, int T, int N, int M, int Dx, int Dy) {
 }
 
 extern "C" int psvo_set_tuning(int key, int value) {
-    if (key == PSVO_TUNE_BSIM_BWD && value >= -1 && value <= 3) {
+    if (key == PSVO_TUNE_BSIM_BWD && value >= -1 && value <= 4) {
         g_bsim_bwd_variant = value;
         return PSVO_OK;
     }

@@ -99,6 +99,31 @@ __device__ __forceinline__ void row_reduce_scatter(const float (&v)[4 * K], floa
 }
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+
+// f32 -> three bf16 pieces by truncation (v == hi + mid + lo exactly: 8 + 8 + 8 significand bits), returned as 16-bit
+// patterns.  Two such triples (a, b) give a b = ah bh + ah bm + am bh + ah bl + al bh + am bm + am bl + al bm up to the
+// al bl term (2^-32 relative): the eight K slots one lane feeds to v_mfma_f32_16x16x32_bf16.
+__device__ __forceinline__ void bf16_split3(float v, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+    const float r = v - __uint_as_float(hb);
+    const unsigned mb = __float_as_uint(r) & 0xffff0000u;
+    const float r2 = r - __uint_as_float(mb);
+    h = hb >> 16;
+    m = mb >> 16;
+    l = __float_as_uint(r2) >> 16;
+}
+// K slots of one component:   A side [ah, ah, am, ah, al, am, am, al]   B side [bh, bm, bh, bl, bh, bm, bl, bm]
+__device__ __forceinline__ uint4 bf16x3_a(float v) {
+    unsigned h, m, l;
+    bf16_split3(v, h, m, l);
+    return make_uint4(h | (h << 16), m | (h << 16), l | (m << 16), m | (l << 16));
+}
+__device__ __forceinline__ uint4 bf16x3_b(float v) {
+    unsigned h, m, l;
+    bf16_split3(v, h, m, l);
+    return make_uint4(h | (m << 16), h | (l << 16), h | (m << 16), l | (m << 16));
+}
 
 // JM = 0: everything on the VALU (per-j sums in registers + swap-add).
 // JM = 1: the per-j sums on v_mfma_f32_16x16x4_f32 (19 % of each tile used: measured slower, kept for the A/B table).
@@ -110,12 +135,18 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 //   R2 = sum_j p F'^2 (U = x' - R1, V = x'^2 - 2 x' R1 + R2 with sum_j p = 1), and sum c u = sum c x' - F' sum c.
 //   The expanded square cancels where the differenced form does not: absolute error ~ 6e-8 (|x'|^2 + |F'|^2) on S, i.e.
 //   4e-6 relative on p at sigma_f = 1 and 2e-4 at sigma_f = 0.1; the gradient tests run this variant at both.
+// JM = 3 (Dx = 2): the same product on v_mfma_f32_16x16x32_bf16 (half the passes of the f32 instruction): every f32
+//   operand is split into three bf16 pieces (bf16_split3) and lane group g -- component g of the K = 4 product -- feeds
+//   its eight K slots with the piece products listed there, so the sum carries the f32 product to 2^-32.  The B side
+//   (per forward particle) is split once per step when the tile is staged and kept in LDS as the operand image: a slot is
+//   [4 components][4 dwords] + F'_0, F'_1 (20 floats); padded entries use W' = -1e30 (finite: -inf has no bf16 split).
 template <int DX, int DY, int H, int M, int JM>
 __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
     using AC = BAcc<DX, DY>;
-    constexpr int PS = BTileSlot<DX>::kFloats;
+    constexpr int PS = (JM == 3) ? 20 : BTileSlot<DX>::kFloats;
+    constexpr int FO = (JM == 3) ? 16 : 0;    // F'_0, F'_1 inside a slot (JM >= 2)
     constexpr int NA = DX + 1;            // per-j accumulators: d F' (DX) and d W^
     constexpr int PART = 2;               // lanes per (chain, m) in the per-(chain, m) phases
     constexpr int G = M * PART;           // lanes per chain
@@ -224,7 +255,15 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
 #pragma unroll
         for (int d = 0; d < DX; ++d) F[d] = raw[d] * rp[d];
         const float W = j < N ? (raw[DX] - l) * kLog2e : ninf;
-        if constexpr (JM == 2) {     // (F'_0, F'_1, W' - |F'|^2, 1): the slot IS the B operand, one component per lane group
+        if constexpr (JM == 3) {     // the four components of JM = 2 as bf16 piece images + F' in f32
+            const float Wf = fmaxf(W, -1e30f);
+            uint4* q = reinterpret_cast<uint4*>(buf + j * PS);
+            q[0] = bf16x3_b(F[0]);
+            q[1] = bf16x3_b(F[DX > 1 ? 1 : 0]);
+            q[2] = bf16x3_b(Wf - (F[0] * F[0] + F[DX > 1 ? 1 : 0] * F[DX > 1 ? 1 : 0]));
+            q[3] = bf16x3_b(1.f);
+            *reinterpret_cast<float4*>(buf + j * PS + 16) = make_float4(F[0], F[DX > 1 ? 1 : 0], 0.f, 0.f);
+        } else if constexpr (JM == 2) {     // (F'_0, F'_1, W' - |F'|^2, 1): the slot IS the B operand, one component per lane group
             *reinterpret_cast<float4*>(buf + j * PS) = make_float4(F[0], F[1], W - (F[0] * F[0] + F[DX > 1 ? 1 : 0] * F[DX > 1 ? 1 : 0]), 1.f);
         } else if constexpr (DX <= 3) {
             float4 v;
@@ -418,22 +457,33 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                     }
                     // JM = 2: A operand of the exponent MFMA: lane (row = j16 -> slot 16 r + j16 of the round, component g)
                     float sop = 0.f;
-                    if constexpr (JM == 2) {
+                    uint4 aop = make_uint4(0u, 0u, 0u, 0u);      // JM = 3: the bf16 piece image of sop
+                    if constexpr (JM >= 2) {
                         const int sl = 16 * r + j16;
                         const float x0 = xw[sl], x1 = xw[CM + sl], l2 = xw[DX * CM + sl];
                         sop = (g == 0) ? 2.f * x0 : (g == 1) ? 2.f * x1 : (g == 2) ? 1.f : -fmaf(x0, x0, fmaf(x1, x1, l2));
+                        if constexpr (JM == 3) aop = bf16x3_a(sop);
                     }
-                    if constexpr (JM == 2) {
-                        // the MFMA of tile jt + 1 is issued before tile jt's exponentials are consumed (its 8 passes then
+                    if constexpr (JM >= 2) {
+                        auto exponents = [&](const float* sp) -> f4v {
+                            if constexpr (JM == 2) {
+                                return __builtin_amdgcn_mfma_f32_16x16x4f32(sop, sp[g], f4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            } else {
+                                const uint4 bq = *reinterpret_cast<const uint4*>(sp + 4 * g);
+                                return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, aop),
+                                                                               __builtin_bit_cast(bf8v, bq),
+                                                                               f4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            }
+                        };
+                        // the MFMA of tile jt + 1 is issued before tile jt's exponentials are consumed (its passes then
                         // run beside this tile's VALU work instead of stalling the wave in front of the first v_exp)
-                        f4v Sn = __builtin_amdgcn_mfma_f32_16x16x4f32(sop, cbase[g], f4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        f4v Sn = exponents(cbase);
 #pragma unroll
                         for (int jt = 0; jt < JC; ++jt) {
                             const float* sp = cbase + jt * 16 * PS;
-                            const float2 F2 = *reinterpret_cast<const float2*>(sp);      // F'_0, F'_1 of slot j
+                            const float2 F2 = *reinterpret_cast<const float2*>(sp + FO);      // F'_0, F'_1 of slot j
                             const f4v S = Sn;
-                            if (jt + 1 < JC)
-                                Sn = __builtin_amdgcn_mfma_f32_16x16x4f32(sop, sp[16 * PS + g], f4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            if (jt + 1 < JC) Sn = exponents(sp + 16 * PS);
                             const f2 pa = f2{exp2_fast(S[0]), exp2_fast(S[1])}, pb = f2{exp2_fast(S[2]), exp2_fast(S[3])};
                             const f2 ca = dla * pa, cb = dlb * pb;
                             const f2 Fv = f2{F2.x, F2.y}, Fq = Fv * Fv;
@@ -480,7 +530,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                             Va[r][d] = pk_fma(pua, ua[d], Va[r][d]);
                             Vb[r][d] = pk_fma(pub, ub[d], Vb[r][d]);
                         }
-                        if constexpr (JM == 0) {
+                        if constexpr (JM != 1) {
                             const f2 cs = ca + cb;
                             A2[jt][DX] += cs.x + cs.y;
 #pragma unroll
@@ -517,8 +567,8 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                     const int jt0 = (JC / 2) * (g >> 1) + (JC / 4) * (g & 1);
 #pragma unroll
                     for (int jt = 0; jt < JC / 4; ++jt) {
-                        if constexpr (JM == 2) {     // sum c u = sum c x' - F'_j sum c
-                            const float2 F2 = *reinterpret_cast<const float2*>(cbase + (jt0 + jt) * 16 * PS);
+                        if constexpr (JM >= 2) {     // sum c u = sum c x' - F'_j sum c
+                            const float2 F2 = *reinterpret_cast<const float2*>(cbase + (jt0 + jt) * 16 * PS + FO);
                             v[jt][0] = fmaf(-F2.x, v[jt][DX], v[jt][0]);
                             v[jt][DX > 1 ? 1 : 0] = fmaf(-F2.y, v[jt][DX], v[jt][DX > 1 ? 1 : 0]);
                         }
@@ -587,7 +637,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                     uv[e] = q4.x; uv[e + 1] = q4.y; uv[e + 2] = q4.z; uv[e + 3] = q4.w;
                 }
                 // (x~-F)/sigma^2 = u / (sigma kappa);  z^2 = u^2 / kappa^2
-                if constexpr (JM == 2) {     // R1, R2 -> U = x' - R1, V = x'^2 - 2 x' R1 + R2   (sum_j p = 1)
+                if constexpr (JM >= 2) {     // R1, R2 -> U = x' - R1, V = x'^2 - 2 x' R1 + R2   (sum_j p = 1)
 #pragma unroll
                     for (int d = 0; d < DX; ++d) {
                         const float xs = x[d] * rp[d], r1 = uv[d], r2 = uv[DX + d];
@@ -792,7 +842,7 @@ template <int DX, int DY, int H, int M>
 static int launch_bsim_bwd2(const BsimBwdArgs& a, const BsimBwdOut& o, int jm, hipStream_t stream) {
     using MQ = MlpLds<DX, H, DX>;
     using MG = MlpLds<DX, H, DY>;
-    constexpr int PS = BTileSlot<DX>::kFloats;
+    const int PS = (jm == 3 && DX == 2) ? 20 : BTileSlot<DX>::kFloats;
     constexpr int UVS = (2 * DX + 3) & ~3;
     int cpb, nblk;
     bsim2_geometry(a.N, M, cpb, nblk);
@@ -801,7 +851,10 @@ static int launch_bsim_bwd2(const BsimBwdArgs& a, const BsimBwdOut& o, int jm, h
                                         4 * (DX + 2) * 32 + 4 * 32 * UVS + 16 + (DX >= 3 ? 4 * (7 * DX + DY) * 64 : 0));
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
-    if (jm == 2 && DX == 2) {
+    if (jm == 3 && DX == 2) {
+        if constexpr (DX == 2)
+            hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 3>), dim3(nblk, a.B), dim3(256), lds, stream, a);
+    } else if (jm == 2 && DX == 2) {
         if constexpr (DX == 2)
             hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 2>), dim3(nblk, a.B), dim3(256), lds, stream, a);
     } else if (jm == 1 && DX == 2) {

@@ -335,7 +335,7 @@ BSIM_BWD_VARIANT_CASES = [c for c in CASES if c[0] == "PSVO"] + [("PSVO", 2, 9, 
                                                                 ("PSVO", 1, 5, 300, 32, 4, 2, 16, True, True)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("case", BSIM_BWD_VARIANT_CASES, ids=lambda c: "-".join(map(str, c)))
 def test_bsim_backward_variants(built_lib, case, variant):
     """psvo_bsim_backward under every PSVO_TUNE_BSIM_BWD setting -- v1 (lane = (chain, half, m), per-j butterflies), v2
@@ -363,7 +363,7 @@ def test_bsim_backward_variants(built_lib, case, variant):
     _check_grads(model, P)
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [1, 3, 4])
 @pytest.mark.parametrize("sigma_f", [1.0, 0.3, 0.1])
 def test_bsim_backward_small_transition_scale(built_lib, variant, sigma_f):
     """The exponent MFMA of variant 3 forms W' - |x' - F'|^2 as an expanded product (2 x'.F' - |x'|^2 - |F'|^2), which

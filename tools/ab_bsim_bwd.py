@@ -18,17 +18,19 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = {
     "a": "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS",
-    "b": "SQ_WAVES SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES "
+    "b": "SQ_WAVES SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES "
          "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F32",
 }
+VARIANTS = (0, 1, 2, 3, 4)
 NAMES = {0: "v1: lane = (chain, half, m), per-j butterflies", 1: "v2: j on lanes, VALU",
-         2: "v2 + per-j sums on MFMA 16x16x4 f32", 3: "v2 + pair exponents on MFMA 16x16x4 f32"}
+         2: "v2 + per-j sums on MFMA 16x16x4 f32", 3: "v2 + pair exponents on MFMA 16x16x4 f32",
+         4: "v2 + pair exponents on MFMA 16x16x32 bf16 (3-piece split)"}
 
 
 def run(workload, out):
     out = os.path.abspath(out)
     os.makedirs(out, exist_ok=True)
-    for v in (0, 1, 2, 3):
+    for v in VARIANTS:
         env = dict(os.environ, PSVO_BSIM_BWD_VARIANT=str(v), PSVO_WORKLOAD=workload, TMPDIR="/tmp")
         with open(os.path.join(out, "bench_v%d.json" % v), "w") as f:
             subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "30",
@@ -63,7 +65,7 @@ def report(src, dst, workload):
              "| variant | kernel ms | step ms | VALU insts / step | VALU-active cycles / step | wave cycles / step | "
              "parked (s_waitcnt, barrier) | issue stalls | LDS insts / step | MFMA insts / step | MFMA busy cycles / step | "
              "MFMA and VALU together | v_exp etc. / step |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
-    for v in (0, 1, 2, 3):
+    for v in VARIANTS:
         try:
             b = json.load(open(os.path.join(src, "bench_v%d.json" % v)))
             a = json.load(open(os.path.join(src, "pmc_a_v%d.json" % v)))
@@ -77,7 +79,7 @@ def report(src, dst, workload):
             NAMES[v], b["config"]["native_ms_per_step"]["psvo_bsim_backward"], b["ms_per_step"],
             a["SQ_INSTS_VALU"] / w / T, 4.0 * a["SQ_ACTIVE_INST_VALU"] / w / T, wc,
             100.0 * a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"], 100.0 * a["SQ_WAIT_INST_ANY"] / a["SQ_WAVE_CYCLES"],
-            a["SQ_INSTS_LDS"] / w / T, m["SQ_INSTS_VALU_MFMA_F32"] / w2 / T, m["SQ_VALU_MFMA_BUSY_CYCLES"] / w2 / T,
+            a["SQ_INSTS_LDS"] / w / T, (m["SQ_INSTS_VALU_MFMA_F32"] + m.get("SQ_INSTS_VALU_MFMA_BF16", 0.0)) / w2 / T, m["SQ_VALU_MFMA_BUSY_CYCLES"] / w2 / T,
             m["SQ_VALU_MFMA_COEXEC_CYCLES"] / w2 / T, m["SQ_INSTS_VALU_TRANS_F32"] / w2 / T))
     open(dst, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
