@@ -35,6 +35,7 @@ class PSVO(SVO):
         # (second side stream for the bsim weight gradients only in the default wiring: otherwise the hoisted
         #  f.mean(mu_0) of the t = 0 term accumulates into the same gradient slice on the main stream)
         both = self.model.use_bootstrap and self.model.use_2_q
+        self._release()
         self._ov = (Overlap(side_stream(obs.device), side_stream(obs.device, 1) if both else None)
                     if (autograd.OVERLAP and obs.is_cuda) else None)
         self._sigmas = self.model.sigmas()          # every scale vector of this evaluation, one fused launch
@@ -44,6 +45,7 @@ class PSVO(SVO):
         log_ZSMC = self.compute_log_ZSMC_bsim(bs["score"])
         log["Xs"] = bs["bwX"].permute(1, 0, 3, 2)                      # (B, T, N, Dx)
         log["filter"], log["bsim"] = filt, bs
+        self._release()
         return log_ZSMC, log
 
     def compute_log_ZSMC_bsim(self, score):
@@ -83,7 +85,7 @@ class PSVO(SVO):
         desc._gbufs = gb if all(v is not None for v in gb) else None
         score, bwX, flp, glp, Omega, sel = BsimFunction.apply(
             desc, obs_TB, eps_b, u_b, sel_in, filt["Fm"], filt["logW"], filt["lse"],
-            *model.f_tran.hip_params(), *model.g_tran.hip_params(), *model.q1_inv_tran.hip_params(),
+            *self._mlp_params(model.f_tran), *self._mlp_params(model.g_tran), *self._mlp_params(model.q1_inv_tran),
             self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
             bmu2, minit, self._sigma(self.BSim_q_init), imean, isig)
         return {"score": score, "bwX": bwX, "flp": flp, "glp": glp, "Omega": Omega, "sel": sel}

@@ -25,6 +25,7 @@ class PSVOwR(PSVO):
         # (second side stream for the bsim weight gradients only in the default wiring: otherwise the hoisted
         #  f.mean(mu_0) of the t = 0 term accumulates into the same gradient slice on the main stream)
         both = self.model.use_bootstrap and self.model.use_2_q
+        self._release()
         self._ov = (Overlap(side_stream(obs.device), side_stream(obs.device, 1) if both else None)
                     if (autograd.OVERLAP and obs.is_cuda) else None)
         self._sigmas = self.model.sigmas()
@@ -35,6 +36,7 @@ class PSVOwR(PSVO):
         log_ZSMC = (bs["lseW"].sum(0) - time * math.log(float(self.n_particles))).mean()
         log["Xs"] = bs["bwXanc"].permute(1, 0, 3, 2)                   # (B, T, N, Dx), PSVOwR.py:198
         log["filter"], log["bsim"] = filt, bs
+        self._release()
         return log_ZSMC, log
 
     def backward_simulation_w_resampling(self, filt, obs, noise=None):
@@ -74,7 +76,7 @@ class PSVOwR(PSVO):
         desc._sticky = self._sticky
         lseW, bwXanc, bwX, bwW, sel, anc, ws = BsimWRFunction.apply(
             desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, filt["Fm"], filt["logW"], filt["lse"],
-            *model.f_tran.hip_params(), *model.g_tran.hip_params(), *model.q1_inv_tran.hip_params(),
+            *self._mlp_params(model.f_tran), *self._mlp_params(model.g_tran), *self._mlp_params(model.q1_inv_tran),
             self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
             bmu2, minit, self._sigma(self.BSim_q_init), imean, isig)
         # ws[-1] (as int32) is nonzero iff an exchange poll of the kernel timed out (check_exchange, the tests)

@@ -47,17 +47,68 @@ class SVO:
         self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
 
         log = {}
+        self._release()
         self._sigmas = self.model.sigmas()          # every scale vector of this evaluation, one fused launch
         filt = self.SMC(hidden, obs, noise=noise)
         log_ZSMC = self.compute_log_ZSMC(filt["lse"])
         # (T, B, Dx, N) -> (batch_size, time, n_particles, Dx)
         log["Xs"] = filt["Xanc"].permute(1, 0, 3, 2)
         log["filter"] = filt
+        self._release()
         return log_ZSMC, log
 
+    def _release(self):
+        """drop what one evaluation cached on the object (scale vectors, hoisted means, features, stream context).
+
+        These tensors carry autograd history; kept until the next call they keep the previous evaluation's graph alive, and
+        with it the parameters' gradient accumulators, which remember the stream they were created on.  The next evaluation
+        would reuse them: issued under a hipGraph capture on another stream the engine then synchronises that old stream
+        into the capture, where it is never joined back (hipStreamEndCapture crashes on ROCm 7.2 instead of reporting it)."""
+        self._sigmas = self._m0 = self._sig0 = self._obs_TB = self._ov = None
+        self.preprocessed_X0 = self.preprocessed_obs = None
+
+    # hidden widths the kernels are instantiated for (template parameter H of csrc/*.hip)
+    _KERNEL_H = (16, 32, 64)
+
+    def _particle_mlps(self):
+        """the MLPs evaluated per particle INSIDE the kernels (one hidden layer each; hip_params() raises otherwise)"""
+        m = self.model
+        trans = [m.q1_tran, m.g_tran]
+        if not m.use_bootstrap:
+            trans.append(m.f_tran)
+        if getattr(m, "q1_inv_tran", None) is not None and hasattr(self, "q1_inv"):
+            trans.append(m.q1_inv_tran)
+        return trans
+
+    def _kernel_width(self):
+        """(H the kernels run at, whether any per-particle MLP is narrower than that).
+
+        The kernels take ONE hidden width for all per-particle MLPs of a launch, from _KERNEL_H.  Other widths the flags can
+        reach (q1_layers=50, g_layers=16 beside q1_layers=32, ...) run at the next instantiated width with zero-padded hidden
+        units: a padded unit is relu(x . 0 + 0) = 0 times a zero row of the output kernel, so values and the gradients of the
+        real entries are unchanged (the padding is `torch.nn.functional.pad` on the parameters: autograd slices the padded
+        gradient back).  Wider than 64 has no kernel: ValueError."""
+        cached = self.__dict__.get("_kw")
+        if cached is None:
+            widths = [t.hip_params()[0].shape[1] for t in self._particle_mlps()]
+            fit = [H for H in self._KERNEL_H if H >= max(widths)]
+            if not fit:
+                raise ValueError("per-particle MLP hidden width %d exceeds the widest kernel instantiation (%d); "
+                                 "no fallback path exists" % (max(widths), self._KERNEL_H[-1]))
+            cached = self._kw = (fit[0], any(w != fit[0] for w in widths))
+        return cached
+
+    def _mlp_params(self, tran):
+        """(W1, b1, W2, b2) of a per-particle MLP at the kernels' hidden width"""
+        W1, b1, W2, b2 = tran.hip_params()
+        pad = self._kernel_width()[0] - W1.shape[1]
+        if pad:
+            F = torch.nn.functional
+            W1, b1, W2 = F.pad(W1, (0, pad)), F.pad(b1, (0, pad)), F.pad(W2, (0, 0, 0, pad))
+        return W1, b1, W2, b2
+
     def _desc(self, M=1):
-        H = self.model.q1_tran.Dhs[0]
-        d = self._make_desc(M, H)
+        d = self._make_desc(M, self._kernel_width()[0])
         d._ov = getattr(self, "_ov", None)          # stream-overlap context of this evaluation (PSVO only)
         return d
 
@@ -67,10 +118,12 @@ class SVO:
             return dist.get_sigma()
         return sig[id(dist)]
 
-    @staticmethod
-    def _gbuf(tran):
-        """slice of the flat gradient buffer a native backward may accumulate this MLP's gradient into"""
-        return None if tran is None else tran.__dict__.get("_flat_grad")
+    def _gbuf(self, tran):
+        """slice of the flat gradient buffer a native backward may accumulate this MLP's gradient into (None when the
+        kernels run on padded copies of the weights: the padded gradient then goes back through autograd)"""
+        if tran is None or self._kernel_width()[1]:
+            return None
+        return tran.__dict__.get("_flat_grad")
 
     def _make_desc(self, M, H):
         return ops.make_desc(self.batch_size, self.time, self.n_particles, M, self.model.Dx, self.model.Dy, H,
@@ -126,7 +179,7 @@ class SVO:
         if self.resample_particles and u is None and idx_in is None:
             u = self._rand(T, B, N, device=dev)
 
-        f_params = (None,) * 4 if model.use_bootstrap else model.f_tran.hip_params()
+        f_params = (None,) * 4 if model.use_bootstrap else self._mlp_params(model.f_tran)
         sig_f = None if model.use_bootstrap else self._sigma(self.f)
         self._m0, self._sig0 = m0, sig0
         desc = self._desc()
@@ -135,7 +188,7 @@ class SVO:
         # one opaque autograd node: psvo_filter_forward / psvo_filter_backward
         lse, Fm, logW, X, Xanc, idx = FilterFunction.apply(
             desc, obs_TB, eps, u, idx_in,
-            *model.q1_tran.hip_params(), *f_params, *model.g_tran.hip_params(),
+            *self._mlp_params(model.q1_tran), *f_params, *self._mlp_params(model.g_tran),
             self._sigma(self.q1), sig_q2, sig_f, self._sigma(self.g), mu2, m0, sig0, fm0, fsig0)
         return {"lse": lse, "Fm": Fm, "logW": logW, "X": X, "Xanc": Xanc, "idx": idx, "eps": eps, "u": u}
 

@@ -78,6 +78,17 @@ def _cf(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _aliases(d):
+    """the tensors of a forward's result dict as fresh aliases (same storage, new tensor objects) for keeping on ctx.
+
+    A Function's output tensors get the node as grad_fn; the very same objects stored on ctx close a reference cycle
+    (node -> ctx -> tensor -> grad_fn) that only the cycle collector frees.  Until it runs, the finished evaluation's graph
+    stays alive and with it the parameters' gradient accumulators, which the next evaluation then REUSES together with the
+    stream they were created on: under a hipGraph capture the engine synchronises that stream into the capture, nothing
+    joins it back, and hipStreamEndCapture fails (or crashes, for the null stream, on ROCm 7.2)."""
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
 def _cg(t):
     return None if t is None else t.contiguous()
 
@@ -123,7 +134,7 @@ class FilterFunction(torch.autograd.Function):
         else:
             filt = ops.filter_forward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
                                       obs_TB, eps, u, idx_in)
-        ctx.desc, ctx.filt = desc, filt
+        ctx.desc, ctx.filt = desc, _aliases(filt)
         ctx.saved = (q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs_TB, eps)
         ctx.mark_non_differentiable(filt["X"], filt["Xanc"], filt["idx"])
         return filt["lse"], filt["Fm"], filt["logW"], filt["X"], filt["Xanc"], filt["idx"]
@@ -211,7 +222,7 @@ class BsimFunction(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         bs = ops.bsim_forward(desc, {**filt, "X": filt["Fm"]}, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit,
                               sig_init, imean, isig, obs_TB, eps_b, u_b, sel_in, save=need)
-        ctx.desc, ctx.filt, ctx.bs = desc, filt, bs
+        ctx.desc, ctx.filt, ctx.bs = desc, filt, _aliases(bs)
         ctx.saved = (f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b)
         ctx.mark_non_differentiable(bs["bwX"], bs["flp"], bs["glp"], bs["Omega"], bs["sel"])
         ctx.set_materialize_grads(False)      # (else the engine zero-fills a gradient for each of the five constants)
@@ -279,7 +290,7 @@ class BsimWRFunction(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         bs = ops.bsimwr_forward(desc, filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean,
                                 isig, obs_TB, eps_b, u_b=u_b, u_r=u_r, sel_in=sel_in, anc_in=anc_in, save=need)
-        ctx.desc, ctx.filt, ctx.bs = desc, filt, bs
+        ctx.desc, ctx.filt, ctx.bs = desc, filt, _aliases(bs)
         _note_exchange(desc, bs["ws"], 1)
         ctx.saved = (f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b)
         ctx.mark_non_differentiable(bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"], bs["ws"])
@@ -352,7 +363,7 @@ class DenseFunction(torch.autograd.Function):
         X, W, b = _cf(X), _cf(W), _cf(b)
         Y = ops.dense_forward(X, W, b, relu)
         ctx.relu, ctx.need_dX = bool(relu), ctx.needs_input_grad[0]
-        ctx.saved = (X, W, Y if relu else None)
+        ctx.saved = (X, W, Y.detach() if relu else None)     # (an alias: see _aliases)
         return Y
 
     @staticmethod
@@ -386,7 +397,7 @@ class BiLSTMFunction(torch.autograd.Function):
         x, W_fw, b_fw, W_bw, b_bw = (_cf(v) for v in (x, W_fw, b_fw, W_bw, b_bw))
         if any(ctx.needs_input_grad):
             out, cs, gates = ops.bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=True)
-            ctx.saved = (x, W_fw, W_bw, out, cs, gates)
+            ctx.saved = (x, W_fw, W_bw, out.detach(), cs, gates)     # (an alias of the output: see _aliases)
         else:
             out = ops.bilstm_forward(x, W_fw, b_fw, W_bw, b_bw)
         return out

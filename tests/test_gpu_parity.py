@@ -66,6 +66,17 @@ EMISSION_CASES = [
 ]
 
 
+# per-particle MLPs of widths the kernels are not instantiated for, and of different widths within one launch: they run at
+# the next instantiated width on zero-padded hidden units (SVO._kernel_width); the hoisted MLPs (q0, q2) of odd widths go
+# through psvo_dense_*.  Reference: any comma-separated widths parse (src/runner_flag.py:198-206, src/model.py:99-151).
+WIDTH_CASES = [
+    (("PSVO", 2, 6, 16, 8, 2, 1, 32, False, True), dict(q1_layers="24", f_layers="40", g_layers="16", q0_layers="20", q2_layers="50")),
+    (("AESMC", 2, 6, 16, 1, 2, 1, 32, True, True), dict(q1_layers="50", g_layers="12")),
+    (("PSVOwR", 2, 5, 12, 4, 2, 1, 16, True, True), dict(q1_layers="10", g_layers="16")),
+    (("SVO", 2, 5, 160, 1, 3, 2, 16, False, False), dict(q1_layers="33", f_layers="64", g_layers="7")),
+]
+
+
 def _setup(obj, B, T, N, M, Dx, Dy, H, bootstrap, two_q, seed=0, **extra):
     from psvo_amd.model import SSM
     from psvo_amd.SMC.SVO import SVO
@@ -396,11 +407,11 @@ def test_bsim_backward_small_transition_scale(built_lib, variant, sigma_f):
     _check_grads(model, P)
 
 
-@pytest.mark.parametrize("case,extra", ENCODER_CASES + EMISSION_CASES, ids=lambda c: "-".join(map(str, c)) if isinstance(c, tuple) else
+@pytest.mark.parametrize("case,extra", ENCODER_CASES + EMISSION_CASES + WIDTH_CASES, ids=lambda c: "-".join(map(str, c)) if isinstance(c, tuple) else
                          ",".join("%s=%s" % kv for kv in c.items()))
 def test_encoder_variants(built_lib, case, extra):
-    """use_stack_rnn=False (two MultiRNNCells), BSim_use_single_RNN (forward cells only) and poisson_emission
-    (psvo_desc.emission = 1): values, indices and every gradient against the oracle."""
+    """use_stack_rnn=False (two MultiRNNCells), BSim_use_single_RNN (forward cells only), poisson_emission
+    (psvo_desc.emission = 1) and odd / mixed hidden widths: values, indices and every gradient against the oracle."""
     obj = case[0]
     FLAGS, model, smc, obs, noise = _setup(*case, seed=7, **extra)
     z_free, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
@@ -495,6 +506,62 @@ def test_psvowr_step_replays_from_hipgraph(built_lib):
         assert torch.isfinite(flat.grad).all()
         assert (flat.grad - g_e).abs().max() <= 1e-5 * float(g_e.abs().max())
     smc.check_exchange()
+
+
+def test_padded_width_step_with_flat_gradients_and_hipgraph(built_lib):
+    """Mixed hidden widths (kernels run on zero-padded copies, gradients return through autograd into the flat buffer's
+    views instead of being accumulated there by the kernels): eager and hipGraph-replayed local steps agree, and the
+    gradient equals the one of the SAME network stored at the kernel width (explicitly padded parameters)."""
+    from psvo_amd.graph import GraphedStep
+    from psvo_amd.optim import FlatParams
+    extra = dict(q1_layers="24", g_layers="16")
+    FLAGS, model, smc, obs, noise = _setup("PSVO", 2, 8, 16, 8, 2, 1, 32, True, True, seed=4, **extra)
+    assert smc._kernel_width() == (32, True)
+    nz = Hh.noise_to_hip(noise, "cuda")
+    flat = FlatParams(model)
+    obs_c = obs.float().cuda()
+
+    def local():
+        flat.zero_grad()
+        z, _ = smc.get_log_ZSMC(obs_c, None, noise=nz)
+        z.backward()
+        return z.detach()
+    z_e = local().clone()
+    g_e = flat.grad.clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(z_e) and float(g_e.abs().max()) > 0
+    step = GraphedStep(local)
+    for _ in range(2):
+        flat.grad.fill_(float("nan"))
+        z_g = step()
+        torch.cuda.synchronize()
+        assert torch.equal(z_g, z_e)
+        assert (flat.grad - g_e).abs().max() <= 1e-5 * float(g_e.abs().max())
+    # the same network at the kernel width: q1 / q1_inv 24 -> 32 and g 16 -> 32 with zero hidden units
+    F2, model2, smc2, _, _ = _setup("PSVO", 2, 8, 16, 8, 2, 1, 32, True, True, seed=4)
+    assert smc2._kernel_width() == (32, False)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in model2.state_dict().items():
+            src = sd[k]
+            if v.shape == src.shape:
+                v.copy_(src)
+            else:
+                v.zero_()
+                v[tuple(slice(0, n) for n in src.shape)].copy_(src)
+    model2.zero_grad()
+    z2, _ = smc2.get_log_ZSMC(obs_c, None, noise=nz)
+    z2.backward()
+    torch.cuda.synchronize()
+    assert abs(float(z2) - float(z_e)) <= 1e-6 * abs(float(z_e))
+    g1 = {k: p.grad for k, p in model.named_parameters()}
+    for k, p in model2.named_parameters():
+        a = g1[k]
+        if a is None or p.grad is None:          # (parameters this objective does not use: None, or zeros in the flat buffer)
+            assert (a is None or float(a.abs().max()) == 0.0) and (p.grad is None or float(p.grad.abs().max()) == 0.0), k
+            continue
+        b = p.grad[tuple(slice(0, n) for n in a.shape)]
+        assert (a - b).abs().max() <= 1e-5 * max(float(b.abs().max()), 1e-6), k
 
 
 def test_psvowr_many_sequences(built_lib):

@@ -8,11 +8,13 @@ while launching on the SIDE stream can therefore be handed a block that queued m
 come from THAT stream's pool, inputs that arrive from another stream are record_stream()'ed when their pointer is taken, and
 whoever consumes the outputs on another stream records them there."""
 import ctypes
+import os
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _busy(stream, ms=30.0):
@@ -85,3 +87,17 @@ def test_cross_stream_tensors_are_recorded(built_lib, monkeypatch):
     for k in ("eps", "u"):
         assert filt[k].data_ptr() in on_side, "filter input %s not recorded on the side stream" % k
     assert len(on_side) >= 8 and len(on_main) >= 4
+
+
+@pytest.mark.timeout(900)
+def test_local_step_captures_without_flat_parameters():
+    """hipGraph capture of objective + reverse pass when the gradients return through autograd (no FlatParams) and when
+    the per-particle MLPs run on padded copies: after an eager evaluation on the null stream the capture must neither
+    leave a stream unjoined nor crash (it did until the autograd Functions stopped storing their own outputs on ctx, a
+    reference cycle that kept the previous graph and its gradient accumulators alive).  One child process per arm."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("capture_probe", os.path.join(ROOT, "tools", "capture_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    bad = probe.run_all(["aesmc+noflat", "psvo+overlap+noflat", "psvo+padded+overlap+flat", "psvowr+overlap+noflat"])
+    assert not bad, bad

@@ -43,6 +43,29 @@ def test_ssm_inventory_and_sharing():
         SSM(Hh.make_flags("AESMC", q1_layers="32,32")).q1_tran.hip_params()
 
 
+def test_kernel_hidden_width_selection():
+    """per-particle MLPs run at the next instantiated kernel width on zero-padded hidden units; wider than 64 raises"""
+    from psvo_amd.SMC.PSVO import PSVO
+    from psvo_amd.SMC.AESMC import AESMC
+    F = Hh.make_flags("PSVO", q1_layers="24", f_layers="40", g_layers="16", use_bootstrap=False)
+    smc = PSVO(SSM(F), F)
+    assert smc._kernel_width() == (64, True)
+    W1, b1, W2, b2 = smc._mlp_params(smc.model.g_tran)
+    assert tuple(W1.shape) == (F.Dx, 64) and tuple(b1.shape) == (64,) and tuple(W2.shape) == (64, F.Dy)
+    assert float(W1[:, 16:].abs().max()) == 0.0 and float(W2[16:].abs().max()) == 0.0
+    assert torch.equal(W1[:, :16], smc.model.g_tran.kernels[0]) and torch.equal(W2[:16], smc.model.g_tran.mu_kernel)
+    assert smc._gbuf(smc.model.g_tran) is None            # padded copies: gradients return through autograd
+    (W1.sum() + W2.sum() + b1.sum()).backward()
+    assert tuple(smc.model.g_tran.kernels[0].grad.shape) == (F.Dx, 16)
+    F = Hh.make_flags("AESMC")                                            # defaults: every MLP 32 wide, no padding
+    smc = AESMC(SSM(F), F)
+    assert smc._kernel_width() == (32, False)
+    assert smc._mlp_params(smc.model.q1_tran)[0] is smc.model.q1_tran.kernels[0]
+    F = Hh.make_flags("AESMC", g_layers="100")
+    with pytest.raises(ValueError):
+        AESMC(SSM(F), F)._kernel_width()
+
+
 def test_poisson_emission_mirror_matches_oracle_on_cpu():
     """FLAGS.poisson_emission: g_dist is the reference's tf_poisson (src/model.py:153-155), a unit-scale normal around
     softplus(MLP_g(x)) + 1e-6 (src/distribution/poisson.py:33-38), with no scale variable"""
