@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PSVO_ABI_VERSION 2
+#define PSVO_ABI_VERSION 3
 
 typedef enum {
     PSVO_OK = 0,
@@ -168,8 +168,9 @@ int psvo_bsim_forward(const psvo_desc* desc,
  *            dscore (B,N) = d loss / d score.
  *  outputs : rows for psvo_mlp_wgrad: xt (T,B,Dx,N,M) sub-particles, dFt (T,B,Dx,N,M) w.r.t.
  *            MLP_f(x~), dGt (T,B,Dy,N,M) w.r.t. MLP_g(x~), dmu1 (T,B,Dx,N) w.r.t. MLP_q1inv(bwX[t+1]);
- *            per-workgroup partials (nblk = psvo_bsim_blocks(desc), to be summed over that axis):
- *            dFm_part (T,B,nblk,Dx,N), dlogW_part (T,B,nblk,N)  -> psvo_filter_backward,
+ *            dFm (T,B,Dx,N), dlogW (T,B,N) = d loss / d (Fm, logW) of the forward filter -> psvo_filter_backward
+ *            (folded in workgroup order, by a second launch of this call, from the per-workgroup partials
+ *            dFm_part (T,B,nblk,Dx,N), dlogW_part (T,B,nblk,N): workspaces, nblk = psvo_bsim_blocks(desc)),
  *            per-chain rows (to be summed over N): dbmu2_rows (T,B,Dx,N), dminit_rows (B,Dx,N),
  *            dimean_rows (B,Dx,N);
  *            scale gradients dsig_f, dsig_q1inv, dsig_bq2, dsig_init, disig (Dx), dsig_g (Dy).
@@ -189,8 +190,8 @@ int psvo_bsim_backward(const psvo_desc* desc,
                        const float* lam2_all, const float* om_all, const float* mu1_all,
                        const float* dscore,
                        float* xt, float* dFt, float* dGt, float* dmu1,
-                       float* dFm_part, float* dlogW_part, float* dbmu2_rows, float* dminit_rows,
-                       float* dimean_rows,
+                       float* dFm_part, float* dlogW_part, float* dFm, float* dlogW,
+                       float* dbmu2_rows, float* dminit_rows, float* dimean_rows,
                        float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
                        float* disig, float* sacc_part, void* stream);
 

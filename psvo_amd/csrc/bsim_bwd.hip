@@ -53,13 +53,14 @@ extern "C" int psvo_bsim_backward(
     const float* sig_bq2, const float* bmu2, const float* minit, const float* sig_init, const float* imean,
     const float* isig, const float* obs, const float* eps_b, const float* bwX, const int32_t* sel,
     const float* lam2_all, const float* om_all, const float* mu1_all, const float* dscore, float* xt, float* dFt,
-    float* dGt, float* dmu1, float* dFm_part, float* dlogW_part, float* dbmu2_rows, float* dminit_rows,
+    float* dGt, float* dmu1, float* dFm_part, float* dlogW_part, float* dFm, float* dlogW, float* dbmu2_rows,
+    float* dminit_rows,
     float* dimean_rows, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
     float* disig, float* sacc_part, void* stream) {
     using namespace psvo;
     if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 || !bmu2 ||
         !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwX || !sel || !lam2_all || !om_all ||
-        !mu1_all || !dscore || !xt || !dFt || !dGt || !dmu1 || !dFm_part || !dlogW_part || !dbmu2_rows ||
+        !mu1_all || !dscore || !xt || !dFt || !dGt || !dmu1 || !dFm_part || !dlogW_part || !dFm || !dlogW || !dbmu2_rows ||
         !dminit_rows || !dimean_rows || !dsig_f || !dsig_g || !dsig_q1inv || !dsig_bq2 || !dsig_init || !disig ||
         !sacc_part)
         return PSVO_ERR_INVALID;
@@ -77,7 +78,7 @@ extern "C" int psvo_bsim_backward(
     a.xt = xt; a.dFt = dFt; a.dGt = dGt; a.dmu1 = dmu1;
     a.dFm_part = dFm_part; a.dlogW_part = dlogW_part; a.dbmu2_rows = dbmu2_rows; a.dminit_rows = dminit_rows;
     a.dimean_rows = dimean_rows; a.sacc_part = sacc_part;
-    BsimBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig};
+    BsimBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig, dFm, dlogW};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int variant = bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy);
     if (variant != 0) {

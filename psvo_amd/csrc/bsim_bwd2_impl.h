@@ -863,8 +863,7 @@ static int launch_bsim_bwd2(const BsimBwdArgs& a, const BsimBwdOut& o, int jm, h
     } else {
         hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 0>), dim3(nblk, a.B), dim3(256), lds, stream, a);
     }
-    hipLaunchKernelGGL((bsim_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc_part, a.B * nblk,
-                       a.sig_q1inv, a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
+    launch_bsim_fold_finalize<DX, DY>(a, o, nblk, stream);
     return launch_status();
 }
 

@@ -622,19 +622,42 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
     }
 }
 
-// fold (B * nblk, NACC) partial sums into scale gradients (see filter_bwd_finalize for the PoG algebra)
+// After the reverse kernel, ONE launch: blocks 0 .. gridDim.x - 2 fold the per-workgroup partials of d Fm / d logW (what the
+// filter's reverse pass waits for) in workgroup order; the last block folds the (B * nblk, NACC) partial sums into the scale
+// gradients (see filter_bwd_finalize for the PoG algebra), one accumulator per wave at a time.
 template <int DX, int DY>
-__global__ void bsim_bwd_finalize(const float* __restrict__ sacc, int rows, const float* sig_q1inv,
-                                  const float* sig_bq2, float* dsig_f, float* dsig_g, float* dsig_q1inv,
-                                  float* dsig_bq2, float* dsig_init, float* disig) {
+__global__ void __launch_bounds__(256) bsim_bwd_fold_finalize(
+    const float* __restrict__ dFm_part, const float* __restrict__ dlogW_part, long long TB, int nblk, int N,
+    float* __restrict__ dFm, float* __restrict__ dlogW, const float* __restrict__ sacc, int rows, const float* sig_q1inv,
+    const float* sig_bq2, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
+    float* disig) {
     using AC = BAcc<DX, DY>;
+    if (blockIdx.x + 1 < gridDim.x) {
+        const long long rowF = (long long)DX * N, nF = TB * rowF, nW = TB * N;
+        long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (e < nF) {            // d Fm (T, B, Dx, N) from (T, B, nblk, Dx, N)
+            const long long tb = e / rowF;
+            const float* p = dFm_part + tb * nblk * rowF + (e - tb * rowF);
+            float v = 0.f;
+            for (int k = 0; k < nblk; ++k) v += p[k * rowF];
+            dFm[e] = v;
+        } else if (e < nF + nW) {   // d logW (T, B, N) from (T, B, nblk, N)
+            e -= nF;
+            const long long tb = e / N;
+            const float* p = dlogW_part + tb * nblk * N + (e - tb * N);
+            float v = 0.f;
+            for (int k = 0; k < nblk; ++k) v += p[(long long)k * N];
+            dlogW[e] = v;
+        }
+        return;
+    }
     __shared__ float tot[AC::kN];
-    const int d = threadIdx.x;
-    for (int k = 0; k < AC::kN; ++k) {  // one wave: lanes stride over the (sequence, workgroup) rows
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    for (int k = wave; k < AC::kN; k += 4) {  // lanes stride over the (sequence, workgroup) rows
         float v = 0.f;
-        for (int r = d; r < rows; r += 64) v += sacc[(size_t)r * AC::kN + k];
+        for (int r = lane; r < rows; r += 64) v += sacc[(size_t)r * AC::kN + k];
         v = wave_sum(v);
-        if (d == 0) tot[k] = v;
+        if (lane == 0) tot[k] = v;
     }
     __syncthreads();
     auto total = [&](int k) { return tot[k]; };
@@ -655,7 +678,17 @@ __global__ void bsim_bwd_finalize(const float* __restrict__ sacc, int rows, cons
 
 struct BsimBwdOut {
     float *dsig_f, *dsig_g, *dsig_q1inv, *dsig_bq2, *dsig_init, *disig;
+    float *dFm, *dlogW;     // folded over the workgroups (the reverse kernels write a.dFm_part / a.dlogW_part)
 };
+
+template <int DX, int DY>
+static inline void launch_bsim_fold_finalize(const BsimBwdArgs& a, const BsimBwdOut& o, int nblk, hipStream_t stream) {
+    const long long TB = (long long)a.T * a.B;
+    const long long n = TB * (DX + 1) * a.N;
+    hipLaunchKernelGGL((bsim_bwd_fold_finalize<DX, DY>), dim3((unsigned)((n + 255) / 256) + 1), dim3(256), 0, stream,
+                       a.dFm_part, a.dlogW_part, TB, nblk, a.N, o.dFm, o.dlogW, a.sacc_part, a.B * nblk, a.sig_q1inv,
+                       a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
+}
 
 static inline void bsim_geometry(int B, int N, int M, int H, int Dx, int& HS, int& NTB, int& cpb, int& nblk) {
     // fewer than two waves per SIMD (1024 SIMDs) with one lane per (chain, m): spread a chain over 2M lanes.
@@ -696,8 +729,7 @@ static int launch_bsim_bwd(const BsimBwdArgs& a, const BsimBwdOut& o, hipStream_
     } else {
         hipLaunchKernelGGL((bsim_bwd_kernel<DX, DY, H, M, 16, 1>), dim3(nblk, a.B), dim3(NTB), lds, stream, a);
     }
-    hipLaunchKernelGGL((bsim_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc_part, a.B * nblk,
-                       a.sig_q1inv, a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
+    launch_bsim_fold_finalize<DX, DY>(a, o, nblk, stream);
     (void)AC::kN;
     return launch_status();
 }

@@ -57,11 +57,16 @@ __global__ void __launch_bounds__(128) rows_mlp_fwd_kernel(const RowsArgs a) {
     }
 }
 
-// ---- backward: 64 rows per workgroup, 4 lanes per row ----------------------------------------------------------------------
+// ---- backward: kRowsBwd rows per workgroup, 256 / kRowsBwd lanes per row ---------------------------------------------------
+// (16 rows: the weight-gradient partial of a workgroup costs NP * rows / 256 dependent LDS steps per thread, and these launches
+//  sit on the dependent chain between the backward simulation and the encoder BPTT -- 64 rows took 106 us for the 6400 x 64
+//  BSim_q2 rows of C* and 54 us for the 32 rows of BSim_q_init)
+constexpr int kRowsBwd = 16;
 template <int H>
 __global__ void __launch_bounds__(256) rows_mlp_bwd_kernel(const RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int RB = 64, HP = H / 4;
+    constexpr int RB = kRowsBwd, LPR = 256 / RB, HP = H / LPR;
+    static_assert(H % LPR == 0, "hidden units split evenly over the lanes of a row");
     const int Din = a.Din, Dout = a.Dout, tid = threadIdx.x;
     const int XS = Din + 1, HS = H + 1;    // padded row strides (bank conflicts)
     float* W1 = smem;                       // [Din][H]
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(256) rows_mlp_bwd_kernel(const RowsArgs a) {
         dos[i] = (o < Dout && r0 + rl < a.R) ? a.dOut[(r0 + rl) * Dout + o] : 0.f;
     }
     __syncthreads();
-    const int rl = tid >> 2, p = tid & 3;
+    const int rl = tid / LPR, p = tid % LPR;
     {   // hidden slice of this lane: pre-activation, h, d h
         float pre[HP];
 #pragma unroll
@@ -105,7 +110,7 @@ __global__ void __launch_bounds__(256) rows_mlp_bwd_kernel(const RowsArgs a) {
     }
     __syncthreads();
     if (a.dX && r0 + rl < a.R) {   // d X[r][i] = sum_k d h[r][k] W1[i][k]
-        for (int i = p; i < Din; i += 4) {
+        for (int i = p; i < Din; i += LPR) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < H; ++k) s = fmaf(dhs[rl * HS + k], W1[i * H + k], s);
@@ -154,9 +159,10 @@ static int launch_rows_fwd(const RowsArgs& a, hipStream_t s) {
 
 template <int H>
 static int launch_rows_bwd(const RowsArgs& a, float* grad, int accumulate, hipStream_t s) {
-    const int nblk = (int)((a.R + 63) / 64);
+    const int nblk = (int)((a.R + kRowsBwd - 1) / kRowsBwd);
     const int NP = a.Din * H + H + H * a.Dout + a.Dout;
-    const size_t lds = sizeof(float) * ((size_t)a.Din * H + H + 4 * H + 64 * (a.Din + 1) + 2 * 64 * (H + 1) + 64 * 4);
+    const size_t lds = sizeof(float) * ((size_t)a.Din * H + H + 4 * H + kRowsBwd * (a.Din + 1) + 2 * kRowsBwd * (H + 1) +
+                                        kRowsBwd * 4);
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
     hipLaunchKernelGGL((rows_mlp_bwd_kernel<H>), dim3(nblk), dim3(256), lds, s, a);
@@ -166,7 +172,7 @@ static int launch_rows_bwd(const RowsArgs& a, float* grad, int accumulate, hipSt
 
 }  // namespace psvo
 
-extern "C" int psvo_rows_mlp_blocks(long long R) { return (int)((R + 63) / 64); }
+extern "C" int psvo_rows_mlp_blocks(long long R) { return (int)((R + psvo::kRowsBwd - 1) / psvo::kRowsBwd); }
 
 extern "C" int psvo_rows_mlp_forward(long long R, int Din, int H, int Dout, const float* X, const psvo_mlp* w,
                                      float* out, void* stream) {

@@ -450,7 +450,7 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
     nblk = lib.psvo_bsim_blocks(ctypes.byref(desc))
     z = lambda *s: _empty(*s, device=dev)
     out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
-           "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N),
+           "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N), "dFm": z(T, B, Dx, N), "dlogW": z(T, B, N),
            "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx)}
     _chain_rows(out, z, T, B, Dx, N)
     sacc = z(B, nblk, lib.psvo_bsim_acc_size(Dx, Dy))
@@ -462,14 +462,13 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
         _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(bs["bwX"]), _ptr(bs["sel"]),
         _ptr(bs["lam2"]), _ptr(bs["om"]), _ptr(bs["mu1"]), _ptr(dscore),
         _ptr(out["xt"]), _ptr(out["dFt"]), _ptr(out["dGt"]), _ptr(out["dmu1"]),
-        _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(out["dbmu2_rows"]), _ptr(out["dminit_rows"]),
-        _ptr(out["dimean_rows"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
+        _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(out["dFm"]), _ptr(out["dlogW"]), _ptr(out["dbmu2_rows"]),
+        _ptr(out["dminit_rows"]), _ptr(out["dimean_rows"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
         _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(sacc), _stream())
     _mark("psvo_bsim_backward", 1)
     _lib.check(st, "psvo_bsim_backward")
-    # fold the per-workgroup partials that feed the filter's reverse pass, then let the caller publish them
-    out["dFm"] = out["dFm_part"].sum(2)
-    out["dlogW"] = out["dlogW_part"].sum(2)
+    # (the call's second launch folded the per-workgroup partials into d Fm / d logW, which feed the filter's reverse
+    #  pass: let the caller publish them)
     if after_kernel is not None:
         after_kernel()
     # weight gradients from rows: MLP_f / MLP_g on the sub-particles, MLP_q1inv on bwX[t+1];
