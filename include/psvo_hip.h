@@ -349,6 +349,11 @@ int psvo_bilstm_backward(int B, int T, int Din, int Dh, const float* x,
                          const float* out, const float* cs, const float* gates, const float* dout,
                          float* dx_part, float* dW_part, float* db_part, void* stream);
 
+/* Folds the per-sequence partials of psvo_bilstm_backward into the two cells' gradients, one launch, fixed order:
+ *   g_fw / g_bw = [kernel (Din+Dh, 4Dh) | bias (4Dh)] of the forward / backward cell; accumulate != 0 adds into them. */
+int psvo_bilstm_wgrad_fold(int B, int Din, int Dh, const float* dW_part, const float* db_part,
+                           float* g_fw, float* g_bw, int accumulate, void* stream);
+
 /* Fused Adam update of one flat fp32 parameter vector: tf.train.AdamOptimizer(lr).minimize(-log_ZSMC)
  * of the reference (src/trainer.py:115-118), TF 1.12 epsilon-hat form.  `step` counts from 1;
  * `grad_scale` multiplies the gradient first (-1/world_size for a summed all-reduce of d log_ZSMC). */
@@ -382,6 +387,11 @@ int psvo_dense_forward(long long R, int Din, int Dout, const float* X, const flo
                        float* Y, void* stream);
 int psvo_dense_backward(long long R, int Din, int Dout, const float* X, const float* Y, const float* dY, const float* W,
                         int relu, float* dX, float* partial, float* grad, int accumulate, void* stream);
+
+/* Measurement aid: a one-thread launch that stores the device's constant-rate wall clock (100 MHz) into *slot when the
+ * stream reaches it.  Captured into a hipGraph beside the real launches it gives the timeline of a REPLAYED step, which
+ * HIP events cannot (event records inside a capture cannot be timed on ROCm) -- tools/replay_timeline.py. */
+int psvo_debug_stamp(unsigned long long* slot, void* stream);
 
 int psvo_selftest_lanes(const float* in64, float* out576, void* stream);
 /* second self-test: swap-add stages over lane bits 5 / 4, 16-lane row sum, and the operand / accumulator layout of

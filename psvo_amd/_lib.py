@@ -66,11 +66,13 @@ SIGNATURES = {
                                            _P, _P, _P, ctypes.c_int, _P]),
     "psvo_bilstm_forward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 8 + [_P]),
     "psvo_bilstm_backward": (ctypes.c_int, [ctypes.c_int] * 4 + [_P] * 10 + [_P]),
+    "psvo_bilstm_wgrad_fold": (ctypes.c_int, [ctypes.c_int] * 3 + [_P] * 4 + [ctypes.c_int, _P]),
     "psvo_adam_step": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_longlong, ctypes.c_float, _P]),
     "psvo_reduce_rows": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, _P, ctypes.c_int, _P]),
     "psvo_sigma_forward": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P]),
     "psvo_sigma_backward": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
+    "psvo_debug_stamp": (ctypes.c_int, [_P, _P]),
     "psvo_selftest_lanes": (ctypes.c_int, [_P, _P, _P]),
     "psvo_selftest_lanes2": (ctypes.c_int, [_P, _P, _P]),
     "psvo_elbo_filter": (ctypes.c_int, [_DESC, _P, _P, _P]),

@@ -6,6 +6,8 @@ backward passes are hand-written persistent kernels (psvo_filter_backward, psvo_
 psvo_mlp_wgrad); everything upstream of them (hoisted per-(b, t) proposal means, the encoder,
 softplus/clamp of the scale parameters) stays in torch autograd.
 """
+import os
+
 import torch
 
 from . import ops
@@ -27,6 +29,8 @@ OVERLAP = True
 # bench.py do); left False, FilterFunction.backward joins the streams itself and gradients are safe to read on return.
 DEFER_JOIN = False
 _PENDING_JOIN = []
+# the backward-simulation node launches the filter's reverse kernel itself, right behind its own (launch_reverse_kernel)
+PRELAUNCH = os.environ.get("PSVO_PRELAUNCH", "1") != "0"
 
 
 def join_deferred():
@@ -60,11 +64,13 @@ class Overlap(object):
         self.filter_done = None
         self.bsim_grads_ready = None
         self.bsim_wgrad_done = None
+        self.pre = None                    # its reverse kernel, launched early by the backward-simulation node
 
 
 def side_stream(device=None, which=0):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     if (dev, which) not in _SIDE:
+        # (a high-priority stream for the filter changed nothing in replayed or eagerly issued steps: measured)
         _SIDE[(dev, which)] = torch.cuda.Stream(device=dev)
     return _SIDE[(dev, which)]
 
@@ -140,6 +146,25 @@ class FilterFunction(torch.autograd.Function):
         return filt["lse"], filt["Fm"], filt["logW"], filt["X"], filt["Xanc"], filt["idx"]
 
     @staticmethod
+    def launch_reverse_kernel(ctx, dlse, dFm, dlogW):
+        """overlap wiring: psvo_filter_backward (kernel, row sums, scale gradients) on the side stream, ordered after the
+        event that publishes the upstream gradients; its weight-gradient launches are left to backward() (r["_wgrad"]).
+        Called by backward(), or EARLY by the backward-simulation node right after its own kernel (PRELAUNCH): the engine
+        runs the encoder's reverse pass before this node (it was created earlier in the forward pass), and in a replayed
+        hipGraph the reverse filter kernel then started ~75 us after its inputs existed, behind those launches."""
+        desc = ctx.desc
+        q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs_TB, eps = ctx.saved
+        ov = desc._ov
+        ov.side.wait_event(ov.bsim_grads_ready)
+        with ops.launch_on(ov.side):
+            r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
+                                    obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
+                                    gbufs=ctx.gbufs, defer_wgrad=True)
+        kernel_done = torch.cuda.Event()
+        kernel_done.record(ov.side)              # the reverse kernel's own outputs (d mu2, d m0, scale sums) exist
+        return {"r": r, "kernel_done": kernel_done, "grads": (dlse, dFm, dlogW)}
+
+    @staticmethod
     def backward(ctx, dlse, dFm, dlogW, *_):
         desc = ctx.desc
         q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs_TB, eps = ctx.saved
@@ -147,29 +172,26 @@ class FilterFunction(torch.autograd.Function):
         side = None if ov is None else ov.side
         ready = None if ov is None else ov.bsim_grads_ready
         if side is not None and ready is not None:
-            # upstream gradients were produced by BsimFunction.backward (event `ready`); everything issued
+            # upstream gradients were produced by the backward-simulation node (event `ready`); everything issued
             # on the main stream since then (bsim weight gradients, hoisted backward, encoder BPTT) overlaps
             main = torch.cuda.current_stream()
-            side.wait_event(ready)
-
-            entered = torch.cuda.Event()
-            entered.record(main)
-
-            def before_wgrad():
-                # other writers of the flat-gradient slices the filter's weight gradients accumulate into (q1 / f, g):
-                # the bsim weight gradients (event below) and, outside the default wiring, the hoisted f.mean(mu_0) on
-                # the main stream -- only then wait for everything the main stream issued before this node (with the
-                # second side stream in use there is no such writer, and waiting would serialise behind the encoder BPTT)
-                kernel_done.record(side)                 # the reverse kernel's own outputs (d mu2, d m0, scale sums) exist
-                if ov.side2 is None:
-                    side.wait_event(entered)
-                if ov.bsim_wgrad_done is not None:       # (recorded on the second side stream when used)
-                    side.wait_event(ov.bsim_wgrad_done)
-            kernel_done = torch.cuda.Event()
+            pre, ov.pre = ov.pre, None
+            same = lambda a, b: (a is None and b is None) or (a is not None and b is not None
+                                                              and a.data_ptr() == b.data_ptr() and a.shape == b.shape)
+            if pre is None or not all(same(a, b) for a, b in zip(pre["grads"], (dlse, dFm, dlogW))):
+                # not launched early, or the engine added further contributions to the upstream gradients
+                pre = FilterFunction.launch_reverse_kernel(ctx, dlse, dFm, dlogW)
+            r, kernel_done = pre["r"], pre["kernel_done"]
+            # other writers of the flat-gradient slices the filter's weight gradients accumulate into (q1 / f, g):
+            # the bsim weight gradients (event below) and, outside the default wiring, the hoisted f.mean(mu_0) on
+            # the main stream -- only then wait for everything the main stream issued before this node (with the
+            # second side stream in use there is no such writer, and waiting would serialise behind the encoder BPTT)
+            if ov.side2 is None:
+                side.wait_stream(main)
+            if ov.bsim_wgrad_done is not None:       # (recorded on the second side stream when used)
+                side.wait_event(ov.bsim_wgrad_done)
             with ops.launch_on(side):
-                r = ops.filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
-                                        obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
-                                        gbufs=ctx.gbufs, before_wgrad=before_wgrad)
+                r.pop("_wgrad")()
             if ctx.gbufs is not None and DEFER_JOIN:
                 # the weight gradients accumulate straight into the flat gradient buffer: nothing downstream on the main
                 # stream reads them, so the main stream (hoisted q2 / q0 backward, scale gradients) continues as soon as
@@ -200,6 +222,16 @@ class FilterFunction(torch.autograd.Function):
             r["dmu2"] if two_q else None, r["dm0"], r["dsig0"], r["dfm0"], r["dfsig0"])
 
 
+def _filter_node_of(Fm, ov):
+    """the FilterFunction node that produced `Fm` in this evaluation (its ctx), if the overlap wiring is on: the
+    backward-simulation node may launch that node's reverse kernel early.  (A downstream reference only: this node
+    already holds the filter node through its graph edge, so nothing new is kept alive.)"""
+    node = getattr(Fm, "grad_fn", None)
+    if ov is None or node is None or getattr(node, "desc", None) is None or getattr(node.desc, "_ov", None) is not ov:
+        return None
+    return node if hasattr(node, "filt") and hasattr(node, "saved") else None
+
+
 class BsimFunction(torch.autograd.Function):
     """psvo_bsim_forward / psvo_bsim_backward.
 
@@ -218,6 +250,7 @@ class BsimFunction(torch.autograd.Function):
         ov = getattr(desc, "_ov", None)
         if ov is not None and ov.filter_done is not None:     # the filter ran on the side stream
             torch.cuda.current_stream().wait_event(ov.filter_done)
+        ctx.filter_node = _filter_node_of(Fm, ov)
         ctx.gbufs = getattr(desc, "_gbufs", None)             # (f, g, q1_inv) flat-gradient slices or None
         need = any(ctx.needs_input_grad)
         bs = ops.bsim_forward(desc, {**filt, "X": filt["Fm"]}, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit,
@@ -236,10 +269,14 @@ class BsimFunction(torch.autograd.Function):
         f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b = ctx.saved
         ov = getattr(desc, "_ov", None)
 
-        def after_kernel():   # d Fm / d logW exist: the filter's reverse pass (side stream) may start
+        def after_kernel(out):   # d Fm / d logW exist: the filter's reverse pass (side stream) may start
             if ov is not None:
                 ov.bsim_grads_ready = torch.cuda.Event()
                 ov.bsim_grads_ready.record()
+                if PRELAUNCH and ctx.filter_node is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]):
+                    # (lse receives no gradient from this node: d lse is None unless the loss reads lse itself, in which
+                    #  case backward() sees other upstream gradients than these and launches again)
+                    ov.pre = FilterFunction.launch_reverse_kernel(ctx.filter_node, None, out["dFm"], out["dlogW"])
         ws = None if (ov is None or ctx.gbufs is None) else ov.side2
         r = ops.bsim_backward(desc, ctx.filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
                               imean, isig, obs_TB, eps_b, ctx.bs, _cg(dscore), gbufs=ctx.gbufs,
@@ -286,6 +323,7 @@ class BsimWRFunction(torch.autograd.Function):
         ov = getattr(desc, "_ov", None)
         if ov is not None and ov.filter_done is not None:
             torch.cuda.current_stream().wait_event(ov.filter_done)
+        ctx.filter_node = _filter_node_of(Fm, ov)
         ctx.gbufs = getattr(desc, "_gbufs", None)
         need = any(ctx.needs_input_grad)
         bs = ops.bsimwr_forward(desc, filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean,
@@ -305,10 +343,12 @@ class BsimWRFunction(torch.autograd.Function):
         f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig, obs_TB, eps_b = ctx.saved
         ov = getattr(desc, "_ov", None)
 
-        def after_kernel():
+        def after_kernel(out):
             if ov is not None:
                 ov.bsim_grads_ready = torch.cuda.Event()
                 ov.bsim_grads_ready.record()
+                if PRELAUNCH and ctx.filter_node is not None and (ctx.needs_input_grad[7] or ctx.needs_input_grad[8]):
+                    ov.pre = FilterFunction.launch_reverse_kernel(ctx.filter_node, out["dlse"], out["dFm"], out["dlogW"])
         ws = None if (ov is None or ctx.gbufs is None) else ov.side2
         r = ops.bsimwr_backward(desc, ctx.filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
                                 imean, isig, obs_TB, eps_b, ctx.bs, _cg(dlseW), gbufs=ctx.gbufs,
@@ -405,7 +445,8 @@ class BiLSTMFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, W_fw, W_bw, out, cs, gates = ctx.saved
-        dx, dWf, dbf, dWb, dbb = ops.bilstm_backward(x, W_fw, W_bw, out, cs, gates, _cg(dout), gbufs=ctx.gbufs)
+        dx, dWf, dbf, dWb, dbb = ops.bilstm_backward(x, W_fw, W_bw, out, cs, gates, _cg(dout), gbufs=ctx.gbufs,
+                                                     need_dx=ctx.needs_input_grad[1])
         return None, dx, dWf, dbf, dWb, dbb
 
 

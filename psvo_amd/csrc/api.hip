@@ -220,6 +220,17 @@ __global__ void lane_selftest2_kernel(const float* __restrict__ in, float* __res
 }
 }  // namespace psvo
 
+namespace psvo {
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+}  // namespace psvo
+
+extern "C" int psvo_debug_stamp(unsigned long long* slot, void* stream) {
+    if (!slot) return PSVO_ERR_INVALID;
+    psvo::clear_hip_error();
+    hipLaunchKernelGGL(psvo::stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), slot);
+    return psvo::launch_status();
+}
+
 extern "C" int psvo_selftest_lanes2(const float* in192, float* out320, void* stream) {
     if (!in192 || !out320) return PSVO_ERR_INVALID;
     psvo::clear_hip_error();

@@ -175,7 +175,35 @@ static int lstm_bwd_dispatch_dh(const LstmBwdArgs& a, int Dh, hipStream_t s) {
     return launch_status();
 }
 
+// [kernel (K, 4Dh) | bias (4Dh)] of each direction (+)= sum over the B per-sequence partials, fixed order; one launch
+__global__ void bilstm_wgrad_fold_kernel(const float* __restrict__ dW_part, const float* __restrict__ db_part, int B, int KG,
+                                         int G4, float* __restrict__ g_fw, float* __restrict__ g_bw, int accumulate) {
+    const int per = KG + G4;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * per) return;
+    const int dir = e / per, p = e - dir * per;
+    float s = 0.f;
+    if (p < KG) {
+        for (int b = 0; b < B; ++b) s += dW_part[((size_t)b * 2 + dir) * KG + p];
+    } else {
+        for (int b = 0; b < B; ++b) s += db_part[((size_t)b * 2 + dir) * G4 + (p - KG)];
+    }
+    float* g = dir ? g_bw : g_fw;
+    g[p] = accumulate ? g[p] + s : s;
+}
+
 }  // namespace psvo
+
+extern "C" int psvo_bilstm_wgrad_fold(int B, int Din, int Dh, const float* dW_part, const float* db_part, float* g_fw,
+                                      float* g_bw, int accumulate, void* stream) {
+    using namespace psvo;
+    if (!dW_part || !db_part || !g_fw || !g_bw || B <= 0 || Din <= 0 || Dh <= 0) return PSVO_ERR_INVALID;
+    const int G4 = 4 * Dh, KG = (Din + Dh) * G4, n = 2 * (KG + G4);
+    clear_hip_error();
+    hipLaunchKernelGGL(bilstm_wgrad_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dW_part, db_part, B, KG, G4, g_fw, g_bw, accumulate);
+    return launch_status();
+}
 
 extern "C" int psvo_bilstm_backward(int B, int T, int Din, int Dh, const float* x, const float* W_fw,
                                     const float* W_bw, const float* out, const float* cs, const float* gates,

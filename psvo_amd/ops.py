@@ -374,7 +374,7 @@ def split_mlp_grad(g, Din, H, Dout):
 
 
 def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs, eps, filt,
-                    dlse=None, dFm=None, dlogW=None, gbufs=None, before_wgrad=None):
+                    dlse=None, dFm=None, dlogW=None, gbufs=None, before_wgrad=None, defer_wgrad=False):
     """psvo_filter_backward + psvo_mlp_wgrad.  `filt` = forward outputs.  dFm (T,B,Dx,N) / dlogW (T,B,N)
     are upstream gradients (or None).  Returns a dict of gradients."""
     lib = _lib.load()
@@ -403,12 +403,18 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
     _lib.check(st, "psvo_filter_backward")
     # weight gradients from rows; gbufs = (q1, f, g) slices of the flat gradient buffer to accumulate into
     # directly (then no gradient tensor is returned for that MLP), or None
+    gb = gbufs or (None, None, None)
+
+    def wgrad():
+        out["gq1"] = mlp_wgrad(filt["X"], out["dP"], q1, Dx, H, Dx, grad=gb[0])
+        out["gf"] = None if desc.bootstrap else mlp_wgrad(filt["X"], out["dF"], f, Dx, H, Dx, grad=gb[1])
+        out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy, grad=gb[2])
+    if defer_wgrad:          # the caller issues them later (out["_wgrad"]()), e.g. after other writers of the same slices
+        out["_wgrad"] = wgrad
+        return out
     if before_wgrad is not None:
         before_wgrad()
-    gb = gbufs or (None, None, None)
-    out["gq1"] = mlp_wgrad(filt["X"], out["dP"], q1, Dx, H, Dx, grad=gb[0])
-    out["gf"] = None if desc.bootstrap else mlp_wgrad(filt["X"], out["dF"], f, Dx, H, Dx, grad=gb[1])
-    out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy, grad=gb[2])
+    wgrad()
     return out
 
 
@@ -470,7 +476,7 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
     # (the call's second launch folded the per-workgroup partials into d Fm / d logW, which feed the filter's reverse
     #  pass: let the caller publish them)
     if after_kernel is not None:
-        after_kernel()
+        after_kernel(out)
     # weight gradients from rows: MLP_f / MLP_g on the sub-particles, MLP_q1inv on bwX[t+1];
     # gbufs = (f, g, q1_inv) slices of the flat gradient buffer to accumulate into directly, or None
     # wgrad_stream (only with gbufs: nothing is returned that the caller would read): issue the weight gradients on
@@ -566,7 +572,7 @@ def bsimwr_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, 
     out["dlogW"] = out["dlogW_part"].sum(2)
     out["dlse"] = out["dlse_part"].sum(2)
     if after_kernel is not None:
-        after_kernel()
+        after_kernel(out)
     gb = gbufs or (None, None, None)
     with _wgrad_on(wgrad_stream if gbufs is not None else None):
         out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx, grad=gb[0])
@@ -597,8 +603,8 @@ def sigma_backward(raw, mins, dsig, graw, accumulate=True):
     return graw
 
 
-def bilstm_backward(x, W_fw, W_bw, out, cs, gates, dout, gbufs=None):
-    """psvo_bilstm_backward -> (dx (B,T,Din), dW_fw, db_fw, dW_bw, db_bw)."""
+def bilstm_backward(x, W_fw, W_bw, out, cs, gates, dout, gbufs=None, need_dx=True):
+    """psvo_bilstm_backward -> (dx (B,T,Din) or None, dW_fw, db_fw, dW_bw, db_bw)."""
     lib = _lib.load()
     B, T, Din = x.shape
     Dh = W_fw.shape[1] // 4
@@ -613,13 +619,12 @@ def bilstm_backward(x, W_fw, W_bw, out, cs, gates, dout, gbufs=None):
                                   _ptr(dout), _ptr(dx_part), _ptr(dW_part), _ptr(db_part), _stream())
     _mark("psvo_bilstm_backward", 1)
     _lib.check(st, "psvo_bilstm_backward")
-    dx = dx_part.sum(0)
+    dx = dx_part.sum(0) if need_dx else None     # (the first layer's input is the observations: no gradient wanted)
     K, G4 = Din + Dh, 4 * Dh
     if gbufs is not None and gbufs[0] is not None and gbufs[1] is not None:
-        # fold the per-sequence partials straight into the flat gradient buffer: [kernel (K,4Dh) | bias (4Dh)]
-        for d, gb in enumerate(gbufs):
-            reduce_rows(dW_part[:, d], B, 2 * K * G4, K * G4, gb[:K * G4], accumulate=True)
-            reduce_rows(db_part[:, d], B, 2 * G4, G4, gb[K * G4:], accumulate=True)
+        # fold the per-sequence partials straight into the flat gradient buffer: [kernel (K,4Dh) | bias (4Dh)] per cell
+        _lib.check(lib.psvo_bilstm_wgrad_fold(B, Din, Dh, _ptr(dW_part), _ptr(db_part), _ptr(gbufs[0]), _ptr(gbufs[1]), 1,
+                                              _stream()), "psvo_bilstm_wgrad_fold")
         return dx, None, None, None, None
     dW = dW_part.sum(0)
     db = db_part.sum(0)
