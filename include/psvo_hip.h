@@ -83,6 +83,9 @@ const char* psvo_status_string(int status);
  *     operand split into three bf16 pieces (Dx = 2; otherwise as 1).  It changes psvo_bsim_blocks():
  *     set it before sizing workspaces. */
 #define PSVO_TUNE_BSIM_BWD 1
+/*   PSVO_TUNE_ROWS_BWD: rows per workgroup of psvo_rows_mlp_backward: 0 = chosen by the number of rows (default), 16, 64.
+ *     It changes psvo_rows_mlp_blocks(): set it before sizing workspaces. */
+#define PSVO_TUNE_ROWS_BWD 2
 int psvo_set_tuning(int key, int value);          /* PSVO_OK or PSVO_ERR_INVALID */
 int psvo_get_tuning(int key);
 

@@ -13,7 +13,8 @@ PSVO_OK = 0
 PSVO_ERR_INVALID = -1
 PSVO_ERR_UNSUPPORTED = -2
 PSVO_ERR_HIP = -3
-PSVO_TUNE_BSIM_BWD = 1      # psvo_set_tuning key (include/psvo_hip.h)
+PSVO_TUNE_BSIM_BWD = 1      # psvo_set_tuning keys (include/psvo_hip.h)
+PSVO_TUNE_ROWS_BWD = 2
 
 
 class PsvoHipError(RuntimeError):

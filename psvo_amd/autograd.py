@@ -31,10 +31,20 @@ DEFER_JOIN = False
 _PENDING_JOIN = []
 # the backward-simulation node launches the filter's reverse kernel itself, right behind its own (launch_reverse_kernel)
 PRELAUNCH = os.environ.get("PSVO_PRELAUNCH", "1") != "0"
+# ... and leaves its own weight-gradient launches (second side stream) to be issued when the engine reaches the filter node,
+# i.e. BEHIND the small launches of the encoder's reverse chain, which otherwise run beside them on a full card
+DEFER_BSIM_WGRAD = os.environ.get("PSVO_DEFER_BSIM_WGRAD", "1") != "0"
+_PENDING_WORK = []
 
 
 def join_deferred():
     """order the current stream after the side-stream launches that backward() left running (no-op if none)"""
+    while _PENDING_WORK:        # (deferred launches nobody issued: the filter node did not run)
+        ov = _PENDING_WORK.pop()
+        fn, ov.pending_wgrad = ov.pending_wgrad, None
+        if fn is not None:
+            fn()
+            _PENDING_JOIN.append(ov.side2)
     cur = torch.cuda.current_stream() if _PENDING_JOIN else None
     while _PENDING_JOIN:
         cur.wait_stream(_PENDING_JOIN.pop())
@@ -64,6 +74,7 @@ class Overlap(object):
         self.filter_done = None
         self.bsim_grads_ready = None
         self.bsim_wgrad_done = None
+        self.pending_wgrad = None          # the backward simulation's weight-gradient launches, when deferred
         self.pre = None                    # its reverse kernel, launched early by the backward-simulation node
 
 
@@ -188,6 +199,9 @@ class FilterFunction(torch.autograd.Function):
             # second side stream in use there is no such writer, and waiting would serialise behind the encoder BPTT)
             if ov.side2 is None:
                 side.wait_stream(main)
+            if ov.pending_wgrad is not None:         # the backward simulation's weight gradients, deferred until now
+                fn, ov.pending_wgrad = ov.pending_wgrad, None
+                fn()
             if ov.bsim_wgrad_done is not None:       # (recorded on the second side stream when used)
                 side.wait_event(ov.bsim_wgrad_done)
             with ops.launch_on(side):
@@ -197,8 +211,8 @@ class FilterFunction(torch.autograd.Function):
                 # stream reads them, so the main stream (hoisted q2 / q0 backward, scale gradients) continues as soon as
                 # the reverse KERNEL is done and the weight-gradient launches overlap it; the caller joins the streams once,
                 # after backward() and before it touches the gradients (autograd.join_deferred(): trainer, bench).
-                # (Also moving MLP_g's weight gradient to the second side stream, beside MLP_q1's, crashed
-                #  hipStreamEndCapture on ROCm 7.2 and was dropped: ~20 us.)
+                # (Issuing MLP_g's weight gradient on the second side stream, beside MLP_q1's, takes the process down
+                #  inside hipStreamEndCapture on ROCm 7.2 -- tried twice this round, ~20 us at stake -- and is not done.)
                 main.wait_event(kernel_done)
                 _PENDING_JOIN.extend(st for st in (side, ov.side2) if st is not None)
             else:
@@ -278,10 +292,23 @@ class BsimFunction(torch.autograd.Function):
                     #  case backward() sees other upstream gradients than these and launches again)
                     ov.pre = FilterFunction.launch_reverse_kernel(ctx.filter_node, None, out["dFm"], out["dlogW"])
         ws = None if (ov is None or ctx.gbufs is None) else ov.side2
+        defer = (DEFER_BSIM_WGRAD and DEFER_JOIN and PRELAUNCH and ws is not None and ctx.filter_node is not None
+                 and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]))
         r = ops.bsim_backward(desc, ctx.filt, f, g, q, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init,
                               imean, isig, obs_TB, eps_b, ctx.bs, _cg(dscore), gbufs=ctx.gbufs,
-                              after_kernel=after_kernel, wgrad_stream=ws)
-        if ov is not None:
+                              after_kernel=after_kernel, wgrad_stream=ws, defer_wgrad=defer)
+        if defer:
+            ready, issue_wgrad = ov.bsim_grads_ready, r.pop("_wgrad")
+
+            def issue():
+                ws.wait_event(ready)                 # (after the reverse kernel and its fold, not after what main issued since)
+                with ops.launch_on(ws):
+                    issue_wgrad()
+                ov.bsim_wgrad_done = torch.cuda.Event()
+                ov.bsim_wgrad_done.record(ws)
+            ov.pending_wgrad = issue
+            _PENDING_WORK.append(ov)                 # (join_deferred() issues it if the filter node never runs)
+        elif ov is not None:
             ov.bsim_wgrad_done = torch.cuda.Event()
             ov.bsim_wgrad_done.record(ws if ws is not None else torch.cuda.current_stream())
         Dx, Dy, H = desc.Dx, desc.Dy, desc.H

@@ -27,7 +27,13 @@ static int bsim_bwd_variant(int B, int T, int N, int M, int Dx, int Dy) {
     return v;
 }
 
+namespace psvo {
+int set_rows_bwd_rb(int v);     // rows_mlp.hip
+int get_rows_bwd_rb();
+}  // namespace psvo
+
 extern "C" int psvo_set_tuning(int key, int value) {
+    if (key == PSVO_TUNE_ROWS_BWD) return psvo::set_rows_bwd_rb(value);
     if (key == PSVO_TUNE_BSIM_BWD && value >= -1 && value <= 4) {
         g_bsim_bwd_variant = value;
         return PSVO_OK;
@@ -35,7 +41,10 @@ extern "C" int psvo_set_tuning(int key, int value) {
     return PSVO_ERR_INVALID;
 }
 
-extern "C" int psvo_get_tuning(int key) { return key == PSVO_TUNE_BSIM_BWD ? g_bsim_bwd_variant : PSVO_ERR_INVALID; }
+extern "C" int psvo_get_tuning(int key) {
+    if (key == PSVO_TUNE_ROWS_BWD) return psvo::get_rows_bwd_rb();
+    return key == PSVO_TUNE_BSIM_BWD ? g_bsim_bwd_variant : PSVO_ERR_INVALID;
+}
 
 extern "C" int psvo_bsim_blocks(const psvo_desc* desc) {
     if (!desc) return PSVO_ERR_INVALID;

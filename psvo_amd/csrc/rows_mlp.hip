@@ -57,15 +57,23 @@ __global__ void __launch_bounds__(128) rows_mlp_fwd_kernel(const RowsArgs a) {
     }
 }
 
-// ---- backward: kRowsBwd rows per workgroup, 256 / kRowsBwd lanes per row ---------------------------------------------------
-// (16 rows: the weight-gradient partial of a workgroup costs NP * rows / 256 dependent LDS steps per thread, and these launches
-//  sit on the dependent chain between the backward simulation and the encoder BPTT -- 64 rows took 106 us for the 6400 x 64
-//  BSim_q2 rows of C* and 54 us for the 32 rows of BSim_q_init)
-constexpr int kRowsBwd = 16;
-template <int H>
+// ---- backward: RB rows per workgroup, 256 / RB lanes per row -----------------------------------------------------------------
+// RB = 64 for many rows (fewer partials to fold, weights staged once per 64 rows); RB = 16 below kRowsBwdSmall rows, where the
+// launch is a handful of workgroups on the dependent chain between the backward simulation and the encoder BPTT and the
+// per-thread loop over the rows of the workgroup (NP * RB / 256 dependent LDS steps) is what it costs.
+constexpr int kRowsBwdSmall = 1024;
+static int g_rows_bwd_rb = 0;      // psvo_set_tuning(PSVO_TUNE_ROWS_BWD, 0 | 16 | 64): 0 = by the number of rows
+int set_rows_bwd_rb(int v) {
+    if (v != 0 && v != 16 && v != 64) return PSVO_ERR_INVALID;
+    g_rows_bwd_rb = v;
+    return PSVO_OK;
+}
+int get_rows_bwd_rb() { return g_rows_bwd_rb; }
+static inline int rows_bwd_rb(long long R) { return g_rows_bwd_rb ? g_rows_bwd_rb : (R <= kRowsBwdSmall ? 16 : 64); }
+template <int H, int RB>
 __global__ void __launch_bounds__(256) rows_mlp_bwd_kernel(const RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int RB = kRowsBwd, LPR = 256 / RB, HP = H / LPR;
+    constexpr int LPR = 256 / RB, HP = H / LPR;
     static_assert(H % LPR == 0, "hidden units split evenly over the lanes of a row");
     const int Din = a.Din, Dout = a.Dout, tid = threadIdx.x;
     const int XS = Din + 1, HS = H + 1;    // padded row strides (bank conflicts)
@@ -159,20 +167,24 @@ static int launch_rows_fwd(const RowsArgs& a, hipStream_t s) {
 
 template <int H>
 static int launch_rows_bwd(const RowsArgs& a, float* grad, int accumulate, hipStream_t s) {
-    const int nblk = (int)((a.R + kRowsBwd - 1) / kRowsBwd);
+    const int rb = rows_bwd_rb(a.R);
+    const int nblk = (int)((a.R + rb - 1) / rb);
     const int NP = a.Din * H + H + H * a.Dout + a.Dout;
-    const size_t lds = sizeof(float) * ((size_t)a.Din * H + H + 4 * H + kRowsBwd * (a.Din + 1) + 2 * kRowsBwd * (H + 1) +
-                                        kRowsBwd * 4);
+    const size_t lds = sizeof(float) * ((size_t)a.Din * H + H + 4 * H + rb * (a.Din + 1) + 2 * rb * (H + 1) + rb * 4);
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
-    hipLaunchKernelGGL((rows_mlp_bwd_kernel<H>), dim3(nblk), dim3(256), lds, s, a);
+    if (rb == 16) hipLaunchKernelGGL((rows_mlp_bwd_kernel<H, 16>), dim3(nblk), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((rows_mlp_bwd_kernel<H, 64>), dim3(nblk), dim3(256), lds, s, a);
     hipLaunchKernelGGL(rows_reduce_partials_kernel, dim3(NP), dim3(64), 0, s, a.partial, nblk, NP, grad, accumulate);
     return launch_status();
 }
 
 }  // namespace psvo
 
-extern "C" int psvo_rows_mlp_blocks(long long R) { return (int)((R + psvo::kRowsBwd - 1) / psvo::kRowsBwd); }
+extern "C" int psvo_rows_mlp_blocks(long long R) {
+    const int rb = psvo::rows_bwd_rb(R);
+    return (int)((R + rb - 1) / rb);
+}
 
 extern "C" int psvo_rows_mlp_forward(long long R, int Din, int H, int Dout, const float* X, const psvo_mlp* w,
                                      float* out, void* stream) {

@@ -440,7 +440,7 @@ def sum_chain_rows(out, T, B, Dx):
 
 
 def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig,
-                  obs, eps_b, bs, dscore, gbufs=None, after_kernel=None, wgrad_stream=None):
+                  obs, eps_b, bs, dscore, gbufs=None, after_kernel=None, wgrad_stream=None, defer_wgrad=False):
     """psvo_bsim_backward + psvo_mlp_wgrad.  `bs` = bsim_forward(..., save=True) outputs."""
     lib = _lib.load()
     B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
@@ -482,10 +482,16 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
     # wgrad_stream (only with gbufs: nothing is returned that the caller would read): issue the weight gradients on
     # that stream, ordered after the kernel above, so that the caller's stream is free for what comes next
     gb = gbufs or (None, None, None)
-    with _wgrad_on(wgrad_stream if gbufs is not None else None):
+
+    def wgrad():
         out["gf"] = mlp_wgrad(out["xt"][:T - 1], out["dFt"][:T - 1], f, Dx, H, Dx, grad=gb[0])
         out["gg"] = mlp_wgrad(out["xt"], out["dGt"], g, Dx, H, Dy, grad=gb[1])
         out["gq1inv"] = mlp_wgrad(bs["bwX"][1:], out["dmu1"][:T - 1], q1_inv, Dx, H, Dx, grad=gb[2])
+    if defer_wgrad:      # the caller issues them (out["_wgrad"]() under launch_on(stream), ordered after this kernel)
+        out["_wgrad"] = wgrad
+        return out
+    with _wgrad_on(wgrad_stream if gbufs is not None else None):
+        wgrad()
     return out
 
 
