@@ -171,14 +171,14 @@ int psvo_bsim_forward(const psvo_desc* desc,
  *            dscore (B,N) = d loss / d score.
  *  outputs : rows for psvo_mlp_wgrad: xt (T,B,Dx,N,M) sub-particles, dFt (T,B,Dx,N,M) w.r.t.
  *            MLP_f(x~), dGt (T,B,Dy,N,M) w.r.t. MLP_g(x~), dmu1 (T,B,Dx,N) w.r.t. MLP_q1inv(bwX[t+1]);
- *            dFm (T,B,Dx,N), dlogW (T,B,N) = d loss / d (Fm, logW) of the forward filter -> psvo_filter_backward
- *            (folded in workgroup order, by a second launch of this call, from the per-workgroup partials
- *            dFm_part (T,B,nblk,Dx,N), dlogW_part (T,B,nblk,N): workspaces, nblk = psvo_bsim_blocks(desc)),
- *            per-chain rows (to be summed over N): dbmu2_rows (T,B,Dx,N), dminit_rows (B,Dx,N),
- *            dimean_rows (B,Dx,N);
- *            scale gradients dsig_f, dsig_q1inv, dsig_bq2, dsig_init, disig (Dx), dsig_g (Dy).
- *  sacc_part: workspace, B * nblk * psvo_bsim_acc_size(Dx, Dy) floats.
+ *            per-workgroup partials (nblk = psvo_bsim_blocks(desc)) dFm_part (T,B,nblk,Dx,N), dlogW_part (T,B,nblk,N)
+ *            and sacc_part (B * nblk * psvo_bsim_acc_size(Dx, Dy) floats) for psvo_bsim_backward_fold;
+ *            per-chain rows (to be summed over N): dbmu2_rows (T,B,Dx,N), dminit_rows (B,Dx,N), dimean_rows (B,Dx,N).
  *  The gradient w.r.t. lse is identically zero (the normalised weights' gradients sum to zero).
+ *
+ * psvo_bsim_backward_fold (one launch, to be issued right behind): folds the partials in workgroup order into
+ *            dFm (T,B,Dx,N), dlogW (T,B,N) = d loss / d (Fm, logW) of the forward filter -> psvo_filter_backward, and the
+ *            scale gradients dsig_f, dsig_q1inv, dsig_bq2, dsig_init, disig (Dx), dsig_g (Dy).
  * ------------------------------------------------------------------------------------------- */
 int psvo_bsim_blocks(const psvo_desc* desc);      /* nblk for this problem under the current PSVO_TUNE_BSIM_BWD setting */
 int psvo_bsim_acc_size(int Dx, int Dy);
@@ -193,10 +193,13 @@ int psvo_bsim_backward(const psvo_desc* desc,
                        const float* lam2_all, const float* om_all, const float* mu1_all,
                        const float* dscore,
                        float* xt, float* dFt, float* dGt, float* dmu1,
-                       float* dFm_part, float* dlogW_part, float* dFm, float* dlogW,
+                       float* dFm_part, float* dlogW_part,
                        float* dbmu2_rows, float* dminit_rows, float* dimean_rows,
-                       float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
-                       float* disig, float* sacc_part, void* stream);
+                       float* sacc_part, void* stream);
+int psvo_bsim_backward_fold(const psvo_desc* desc, const float* dFm_part, const float* dlogW_part, const float* sacc_part,
+                            const float* sig_q1inv, const float* sig_bq2, float* dFm, float* dlogW,
+                            float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
+                            float* disig, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PSVOwR: backward simulation with cross-chain resampling and a per-step ELBO.

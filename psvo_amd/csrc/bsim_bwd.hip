@@ -62,16 +62,13 @@ extern "C" int psvo_bsim_backward(
     const float* sig_bq2, const float* bmu2, const float* minit, const float* sig_init, const float* imean,
     const float* isig, const float* obs, const float* eps_b, const float* bwX, const int32_t* sel,
     const float* lam2_all, const float* om_all, const float* mu1_all, const float* dscore, float* xt, float* dFt,
-    float* dGt, float* dmu1, float* dFm_part, float* dlogW_part, float* dFm, float* dlogW, float* dbmu2_rows,
-    float* dminit_rows,
-    float* dimean_rows, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
-    float* disig, float* sacc_part, void* stream) {
+    float* dGt, float* dmu1, float* dFm_part, float* dlogW_part, float* dbmu2_rows, float* dminit_rows,
+    float* dimean_rows, float* sacc_part, void* stream) {
     using namespace psvo;
     if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 || !bmu2 ||
         !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwX || !sel || !lam2_all || !om_all ||
-        !mu1_all || !dscore || !xt || !dFt || !dGt || !dmu1 || !dFm_part || !dlogW_part || !dFm || !dlogW || !dbmu2_rows ||
-        !dminit_rows || !dimean_rows || !dsig_f || !dsig_g || !dsig_q1inv || !dsig_bq2 || !dsig_init || !disig ||
-        !sacc_part)
+        !mu1_all || !dscore || !xt || !dFt || !dGt || !dmu1 || !dFm_part || !dlogW_part || !dbmu2_rows ||
+        !dminit_rows || !dimean_rows || !sacc_part)
         return PSVO_ERR_INVALID;
     if (desc->B <= 0 || desc->T < 2 || desc->N <= 0 || desc->M <= 0) return PSVO_ERR_INVALID;
     if (desc->N > 1024 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
@@ -87,7 +84,7 @@ extern "C" int psvo_bsim_backward(
     a.xt = xt; a.dFt = dFt; a.dGt = dGt; a.dmu1 = dmu1;
     a.dFm_part = dFm_part; a.dlogW_part = dlogW_part; a.dbmu2_rows = dbmu2_rows; a.dminit_rows = dminit_rows;
     a.dimean_rows = dimean_rows; a.sacc_part = sacc_part;
-    BsimBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig, dFm, dlogW};
+    BsimBwdOut o{};      // (the folds are psvo_bsim_backward_fold's)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int variant = bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy);
     if (variant != 0) {
@@ -102,6 +99,44 @@ extern "C" int psvo_bsim_backward(
         case 2: return bb_dispatch_dy<2>(a, o, desc->Dy, desc->H, desc->M, s);
         case 3: return bb_dispatch_dy<3>(a, o, desc->Dy, desc->H, desc->M, s);
         case 4: return bb_dispatch_dy<4>(a, o, desc->Dy, desc->H, desc->M, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
+namespace psvo {
+template <int DX>
+static int fold_dispatch_dy(const BsimBwdArgs& a, const BsimBwdOut& o, int Dy, int nblk, hipStream_t s) {
+    clear_hip_error();
+    switch (Dy) {
+        case 1: launch_bsim_fold_finalize<DX, 1>(a, o, nblk, s); break;
+        case 2: launch_bsim_fold_finalize<DX, 2>(a, o, nblk, s); break;
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}
+}  // namespace psvo
+
+extern "C" int psvo_bsim_backward_fold(const psvo_desc* desc, const float* dFm_part, const float* dlogW_part,
+                                       const float* sacc_part, const float* sig_q1inv, const float* sig_bq2, float* dFm,
+                                       float* dlogW, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2,
+                                       float* dsig_init, float* disig, void* stream) {
+    using namespace psvo;
+    if (!desc || !dFm_part || !dlogW_part || !sacc_part || !sig_q1inv || !sig_bq2 || !dFm || !dlogW || !dsig_f ||
+        !dsig_g || !dsig_q1inv || !dsig_bq2 || !dsig_init || !disig)
+        return PSVO_ERR_INVALID;
+    if (desc->B <= 0 || desc->T < 2 || desc->N <= 0 || desc->M <= 0) return PSVO_ERR_INVALID;
+    BsimBwdArgs a{};
+    a.B = desc->B; a.T = desc->T; a.N = desc->N;
+    a.dFm_part = const_cast<float*>(dFm_part); a.dlogW_part = const_cast<float*>(dlogW_part);
+    a.sacc_part = const_cast<float*>(sacc_part);
+    a.sig_q1inv = sig_q1inv; a.sig_bq2 = sig_bq2;
+    BsimBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig, dFm, dlogW};
+    const int nblk = psvo_bsim_blocks(desc);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (desc->Dx) {
+        case 2: return fold_dispatch_dy<2>(a, o, desc->Dy, nblk, s);
+        case 3: return fold_dispatch_dy<3>(a, o, desc->Dy, nblk, s);
+        case 4: return fold_dispatch_dy<4>(a, o, desc->Dy, nblk, s);
         default: return PSVO_ERR_UNSUPPORTED;
     }
 }

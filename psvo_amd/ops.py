@@ -468,13 +468,19 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
         _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(bs["bwX"]), _ptr(bs["sel"]),
         _ptr(bs["lam2"]), _ptr(bs["om"]), _ptr(bs["mu1"]), _ptr(dscore),
         _ptr(out["xt"]), _ptr(out["dFt"]), _ptr(out["dGt"]), _ptr(out["dmu1"]),
-        _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(out["dFm"]), _ptr(out["dlogW"]), _ptr(out["dbmu2_rows"]),
-        _ptr(out["dminit_rows"]), _ptr(out["dimean_rows"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
-        _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(sacc), _stream())
+        _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(out["dbmu2_rows"]), _ptr(out["dminit_rows"]),
+        _ptr(out["dimean_rows"]), _ptr(sacc), _stream())
     _mark("psvo_bsim_backward", 1)
     _lib.check(st, "psvo_bsim_backward")
-    # (the call's second launch folded the per-workgroup partials into d Fm / d logW, which feed the filter's reverse
-    #  pass: let the caller publish them)
+    # one more launch folds the per-workgroup partials into d Fm / d logW (which feed the filter's reverse pass) and the
+    # scale gradients; then the caller publishes them
+    _mark("psvo_bsim_backward_fold", 0)
+    st = lib.psvo_bsim_backward_fold(
+        ctypes.byref(desc), _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(sacc), _ptr(sig_q1inv), _ptr(sig_bq2),
+        _ptr(out["dFm"]), _ptr(out["dlogW"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
+        _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _stream())
+    _mark("psvo_bsim_backward_fold", 1)
+    _lib.check(st, "psvo_bsim_backward_fold")
     if after_kernel is not None:
         after_kernel(out)
     # weight gradients from rows: MLP_f / MLP_g on the sub-particles, MLP_q1inv on bwX[t+1];
