@@ -54,7 +54,10 @@ typedef struct {
     int32_t M;          /* FLAGS.n_particles_for_BSim_proposal (bsim only)                     */
     int32_t Dx;         /* FLAGS.Dx                                                            */
     int32_t Dy;         /* FLAGS.Dy                                                            */
-    int32_t H;          /* hidden width of q1 / f / g / q1_inv MLPs                            */
+    int32_t H;          /* hidden width of ALL per-particle MLPs of the call (q1 / f / g / q1_inv): 16, 32 or
+                           64.  Narrower or unequal widths (q1_layers=24, g_layers=16): the caller pads W1
+                           columns, b1 and W2 rows with zeros up to H -- a padded unit contributes exactly 0 --
+                           and drops the padded entries of the gradients (psvo_amd/SMC/SVO.py:_mlp_params)   */
     int32_t resample;   /* 1: multinomial resampling every step (SVO/AESMC/PSVO); 0: IWAE      */
     int32_t two_q;      /* FLAGS.use_2_q                                                       */
     int32_t bootstrap;  /* FLAGS.use_bootstrap (f shares q1's MLP and sigma)                   */
