@@ -635,6 +635,29 @@ __global__ void __launch_bounds__(256) bsim_bwd_fold_finalize(
     if (blockIdx.x + 1 < gridDim.x) {
         const long long rowF = (long long)DX * N, nF = TB * rowF, nW = TB * N;
         long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+        if ((N & 3) == 0) {      // four outputs per thread (the launcher sized the grid for it): 16-byte loads
+            e *= 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < nF) {
+                const long long tb = e / rowF;
+                const float* p = dFm_part + tb * nblk * rowF + (e - tb * rowF);
+                for (int k = 0; k < nblk; ++k) {
+                    const float4 q = *reinterpret_cast<const float4*>(p + k * rowF);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                *reinterpret_cast<float4*>(dFm + e) = v;
+            } else if (e < nF + nW) {
+                e -= nF;
+                const long long tb = e / N;
+                const float* p = dlogW_part + tb * nblk * N + (e - tb * N);
+                for (int k = 0; k < nblk; ++k) {
+                    const float4 q = *reinterpret_cast<const float4*>(p + (long long)k * N);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                *reinterpret_cast<float4*>(dlogW + e) = v;
+            }
+            return;
+        }
         if (e < nF) {            // d Fm (T, B, Dx, N) from (T, B, nblk, Dx, N)
             const long long tb = e / rowF;
             const float* p = dFm_part + tb * nblk * rowF + (e - tb * rowF);
@@ -684,7 +707,7 @@ struct BsimBwdOut {
 template <int DX, int DY>
 static inline void launch_bsim_fold_finalize(const BsimBwdArgs& a, const BsimBwdOut& o, int nblk, hipStream_t stream) {
     const long long TB = (long long)a.T * a.B;
-    const long long n = TB * (DX + 1) * a.N;
+    const long long n = TB * (DX + 1) * a.N / ((a.N & 3) == 0 ? 4 : 1);   // (threads: four outputs each when N % 4 == 0)
     hipLaunchKernelGGL((bsim_bwd_fold_finalize<DX, DY>), dim3((unsigned)((n + 255) / 256) + 1), dim3(256), 0, stream,
                        a.dFm_part, a.dlogW_part, TB, nblk, a.N, o.dFm, o.dlogW, a.sacc_part, a.B * nblk, a.sig_q1inv,
                        a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
