@@ -292,6 +292,9 @@ int psvo_bsimwr_backward(const psvo_desc* desc,
  *  sacc    : workspace, psvo_filter_ws_floats(B, T, N, Dx, Dy) floats: B * psvo_filter_acc_size(Dx, Dy)
  *            per-sequence sums followed by the (T,B,Dx,N) per-particle rows of d mu2, which a parallel
  *            kernel sums over N after the time loop.
+ *  Aliasing rule: when fm0 and m0 are the SAME buffer (bootstrap and use_2_q: f_0 is q0's own density,
+ *            SVO.py:86-92) d m0 receives the sum of both gradients and d fm0 is zero; likewise d sig0 / d fsig0 when
+ *            fsig0 and sig0 are the same buffer.
  * ------------------------------------------------------------------------------------------- */
 int psvo_filter_acc_size(int Dx, int Dy);
 long long psvo_filter_ws_floats(int B, int T, int N, int Dx, int Dy);

@@ -150,8 +150,14 @@ class SVO:
         noise = noise or {}
 
         preprocessed_X0, preprocessed_obs = self.preprocess_obs(obs)
-        self.preprocessed_X0, self.preprocessed_obs = preprocessed_X0, preprocessed_obs
         both = model.use_bootstrap and model.use_2_q
+        obs_TB = obs.transpose(0, 1).contiguous().float()
+        self._obs_TB = obs_TB                                                  # (reused by the backward simulation)
+        if not self.smooth_obs and both and obs.dtype == torch.float32:
+            # obs[:, 0] itself is the X0 feature (SVO.py:322-324, no X0_transformer in this wiring): row 0 of the
+            # (T, B, Dy) copy the kernels need anyway is the same data, contiguous -- no second copy launch
+            preprocessed_X0 = obs_TB[0]
+        self.preprocessed_X0, self.preprocessed_obs = preprocessed_X0, preprocessed_obs
 
         # ---- hoisted, particle-independent terms (B*T rows) ------------------------------------
         m0 = self.q0.mean(preprocessed_X0)                                    # (B, Dx)
@@ -160,8 +166,6 @@ class SVO:
             fm0, fsig0 = m0, sig0                                             # f_0 is q0's own density
         else:
             fm0, fsig0 = self.f.mean(preprocessed_X0), self._sigma(self.f)    # SVO.py:91-92
-        obs_TB = obs.transpose(0, 1).contiguous().float()
-        self._obs_TB = obs_TB                                                  # (reused by the backward simulation)
         mu2 = sig_q2 = None
         if model.use_2_q:
             if preprocessed_obs is obs:

@@ -231,9 +231,14 @@ class FilterFunction(torch.autograd.Function):
         gf = none4 if (desc.bootstrap or gb[1] is not None) else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
         gg = none4 if gb[2] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
         two_q, boot = bool(desc.two_q), bool(desc.bootstrap)
+        # (one tensor passed as both m0 and fm0 -- the default wiring -- gets the summed gradient in d m0 from the kernel:
+        #  returning the zero d fm0 as well would only make the engine launch an add; likewise sig0 / fsig0)
+        same_m = m0.data_ptr() == fm0.data_ptr()
+        same_s = sig0.data_ptr() == fsig0.data_ptr()
         return (None, None, None, None, None) + tuple(gq1) + tuple(gf) + tuple(gg) + (
             r["dsig_q1"], r["dsig_q2"] if two_q else None, None if boot else r["dsig_f"], r["dsig_g"],
-            r["dmu2"] if two_q else None, r["dm0"], r["dsig0"], r["dfm0"], r["dfsig0"])
+            r["dmu2"] if two_q else None, r["dm0"], r["dsig0"], None if same_m else r["dfm0"],
+            None if same_s else r["dfsig0"])
 
 
 def _filter_node_of(Fm, ov):

@@ -348,9 +348,10 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
             for (int d = 0; d < DX; ++d) {
                 const float s1 = block_sum(dmean1[d], red, wave, lane, nw);
                 const float s2 = block_sum(dfmean[d], red, wave, lane, nw);
-                if (tid == 0) {
-                    a.dm0[b * DX + d] = s1;
-                    a.dfm0[b * DX + d] = s2;
+                if (tid == 0) {   // (fm0 aliasing m0: ONE tensor feeds both, its gradient is the sum -- see psvo_hip.h)
+                    const bool same0 = (a.fm0 == a.m0);
+                    a.dm0[b * DX + d] = same0 ? s1 + s2 : s1;
+                    a.dfm0[b * DX + d] = same0 ? 0.f : s2;
                 }
             }
         }
@@ -648,9 +649,10 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
             for (int d = 0; d < DX; ++d) {
                 const float s1 = block_sum(one ? dmean1[d] : 0.f, red, wave, lane, nw);
                 const float s2 = block_sum(one ? dfmean[d] : 0.f, red, wave, lane, nw);
-                if (tid == 0) {
-                    a.dm0[b * DX + d] = s1;
-                    a.dfm0[b * DX + d] = s2;
+                if (tid == 0) {   // (fm0 aliasing m0: ONE tensor feeds both, its gradient is the sum -- see psvo_hip.h)
+                    const bool same0 = (a.fm0 == a.m0);
+                    a.dm0[b * DX + d] = same0 ? s1 + s2 : s1;
+                    a.dfm0[b * DX + d] = same0 ? 0.f : s2;
                 }
             }
         }
@@ -688,7 +690,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
 //   else : d s1 = Sc
 template <int DX, int DY>
 __global__ void filter_bwd_finalize(const float* __restrict__ sacc, int B, int two_q, int bootstrap,
-                                    const float* sig_q1, const float* sig_q2, const float* sig0,
+                                    const float* sig_q1, const float* sig_q2, const float* sig0, int same0,
                                     float* dsig_q1, float* dsig_q2, float* dsig_f, float* dsig_g, float* dsig0,
                                     float* dfsig0) {
     using AC = FAcc<DX, DY>;
@@ -719,8 +721,8 @@ __global__ void filter_bwd_finalize(const float* __restrict__ sacc, int B, int t
                 dsig_q1[d] = ds1 + (bootstrap ? dfs : 0.f);
                 dsig_f[d] = bootstrap ? 0.f : dfs;
             } else {
-                dsig0[d] = ds1;
-                dfsig0[d] = dfs;
+                dsig0[d] = same0 ? ds1 + dfs : ds1;      // (fsig0 aliasing sig0: the sum, as for m0 / fm0)
+                dfsig0[d] = same0 ? 0.f : dfs;
             }
         }
         dsig_q2[d] = ds2;
@@ -776,7 +778,7 @@ static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipS
                            a.N, a.dmu2);
     }
     hipLaunchKernelGGL((filter_bwd_finalize<DX, DY>), dim3(1), dim3(64), 0, stream, a.sacc, a.B, a.two_q, a.bootstrap,
-                       a.sig_q1, a.sig_q2, a.sig0, o.dsig_q1, o.dsig_q2, o.dsig_f, o.dsig_g, o.dsig0, o.dfsig0);
+                       a.sig_q1, a.sig_q2, a.sig0, (int)(a.fsig0 == a.sig0), o.dsig_q1, o.dsig_q2, o.dsig_f, o.dsig_g, o.dsig0, o.dfsig0);
     return launch_status();
 }
 
