@@ -291,7 +291,8 @@ def main():
     if args.bsim_bwd_variant >= 0:
         _lib.check(_lib.load().psvo_set_tuning(_lib.PSVO_TUNE_BSIM_BWD, args.bsim_bwd_variant), "psvo_set_tuning")
     dp.init(backend=os.environ.get("PSVO_DIST_BACKEND", "nccl"), device=device)
-    dist = torch.distributed if world > 1 else None
+    # (PSVO_FORCE_PG=1 creates the group for one rank too: RCCL's init, barrier and all-reduce then run on a one-GPU box)
+    dist = torch.distributed if torch.distributed.is_initialized() else None
 
     wl = WORKLOADS[args.workload]
     obj, B, T, N, Dx, Dy, M, H, Dh = wl

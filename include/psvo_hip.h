@@ -22,9 +22,11 @@
  *     (the reference's own internal layout is (T, N, B, D), src/SMC/SVO.py:176-178; the
  *     host mirror permutes to the reference's (B, T, N, Dx) at the Python boundary).
  *   - per-particle MLPs have ONE hidden layer of width H (reference default `*_layers=[32]`,
- *     src/runner_flag.py:53-57); kernels are instantiated for Dx in {2,3,4}, Dy in {1,2},
- *     H in {16,32,64}, M in {4,8,16,32}; N <= 512 (filter, PSVOwR reverse pass), N <= 1024 (backward
- *     simulation); any T, B <= 65535.  Anything else returns PSVO_ERR_UNSUPPORTED (never a silent fallback).
+ *     src/runner_flag.py:53-57) or TWO of the same width (`*_layers=[64, 64]`, the example the reference's flag
+ *     file gives, src/runner_flag.py:50-52; psvo_desc.layers = 2); kernels are instantiated for Dx in {2,3,4},
+ *     Dy in {1,2}, H in {16,32,64} (two layers: {32,64}), M in {4,8,16,32}; N <= 512 (filter, PSVOwR reverse
+ *     pass), N <= 1024 (backward simulation); any T, B <= 65535.  Anything else returns PSVO_ERR_UNSUPPORTED
+ *     (never a silent fallback).
  */
 #ifndef PSVO_HIP_H
 #define PSVO_HIP_H
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PSVO_ABI_VERSION 3
+#define PSVO_ABI_VERSION 4
 
 typedef enum {
     PSVO_OK = 0,
@@ -65,15 +67,24 @@ typedef struct {
                            reference's tf_poisson (src/distribution/poisson.py:27-50) is a UNIT-scale
                            normal whose mean is softplus(MLP_g(x)) + 1e-6: pass sig_g = ones; the
                            dsig_g output is then meaningless                                    */
+    int32_t layers;     /* hidden layers of ALL per-particle MLPs of the call: 0 or 1 = one (psvo_mlp.Wh / bh
+                           ignored), 2 = two layers of width H each (FLAGS.q1_layers="64,64" ...,
+                           src/transformation/MLP.py:24-38,50-54).  An MLP with fewer layers than the others
+                           cannot be padded (an extra relu layer is not the identity): UNSUPPORTED upstream */
 } psvo_desc;
 
-/* One-hidden-layer MLP, keras Dense layout (reference src/transformation/MLP.py:27-46):
- * W1 (Din, H) row-major, b1 (H), W2 (H, Dout) row-major, b2 (Dout). */
+/* Per-particle MLP, keras Dense layout (reference src/transformation/MLP.py:27-46):
+ * hidden_0: W1 (Din, H) row-major, b1 (H); mu_layer: W2 (H, Dout) row-major, b2 (Dout);
+ * with psvo_desc.layers == 2 also hidden_1 between them: Wh (H, H) row-major, bh (H)
+ *     mu = relu(relu(x W1 + b1) Wh + bh) W2 + b2;
+ * Wh / bh are NULL (ignored) for one hidden layer. */
 typedef struct {
     const float* W1;
     const float* b1;
     const float* W2;
     const float* b2;
+    const float* Wh;
+    const float* bh;
 } psvo_mlp;
 
 int psvo_abi_version(void);
@@ -338,6 +349,19 @@ int psvo_rows_mlp_backward(long long R, int Din, int H, int Dout, const float* X
 int psvo_mlp_wgrad_blocks(long long rows);
 int psvo_mlp_wgrad(long long S, int L, int Din, int H, int Dout, const float* X, const float* dOut,
                    const psvo_mlp* w, float* partial, float* grad, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The same for a per-particle MLP with TWO hidden layers of width H in {32, 64} (psvo_desc.layers == 2;
+ * TensorFlow autodiff of MLP_transformation.transform with *_layers = "H,H", reference
+ * src/transformation/MLP.py:24-38,50-54; w->Wh, w->bh required):
+ *   grad = [dW1 (Din,H) | db1 (H) | dWh (H,H) | dbh (H) | dW2 (H,Dout) | db2 (Dout)]  (keras order hidden_0,
+ *   hidden_1, mu_layer; flat).  Rows as psvo_mlp_wgrad.  The three H x H products per row (second-layer
+ *   pre-activations, their input gradient, dWh) run on v_mfma_f32_16x16x4_f32 over LDS tiles of 64 rows.
+ *   partial: workspace, psvo_mlp2_wgrad_blocks(S*L) * len(grad) floats.  accumulate != 0 adds into grad.
+ * ------------------------------------------------------------------------------------------- */
+int psvo_mlp2_wgrad_blocks(long long rows);
+int psvo_mlp2_wgrad(long long S, int L, int Din, int H, int Dout, const float* X, const float* dOut,
+                    const psvo_mlp* w, float* partial, float* grad, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One bidirectional LSTMBlockCell layer over a batch of sequences -- the observation encoder

@@ -83,11 +83,12 @@ class PSVO(SVO):
         desc = self._desc(M)
         gb = (self._gbuf(model.f_tran), self._gbuf(model.g_tran), self._gbuf(model.q1_inv_tran))
         desc._gbufs = gb if all(v is not None for v in gb) else None
+        first, extra = self._mlp_args(self._mlp_params(model.f_tran), self._mlp_params(model.g_tran),
+                                      self._mlp_params(model.q1_inv_tran))
         score, bwX, flp, glp, Omega, sel = BsimFunction.apply(
             desc, obs_TB, eps_b, u_b, sel_in, filt["Fm"], filt["logW"], filt["lse"],
-            *self._mlp_params(model.f_tran), *self._mlp_params(model.g_tran), *self._mlp_params(model.q1_inv_tran),
-            self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
-            bmu2, minit, self._sigma(self.BSim_q_init), imean, isig)
+            *first, self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
+            bmu2, minit, self._sigma(self.BSim_q_init), imean, isig, *extra)
         return {"score": score, "bwX": bwX, "flp": flp, "glp": glp, "Omega": Omega, "sel": sel}
 
     def BS_preprocess_obs(self, obs):

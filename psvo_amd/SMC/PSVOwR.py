@@ -74,11 +74,12 @@ class PSVOwR(PSVO):
         if getattr(self, "_sticky", None) is None or self._sticky.device != dev:
             self._sticky = torch.zeros(1, dtype=torch.int32, device=dev)    # exchange time-outs of ALL launches so far
         desc._sticky = self._sticky
+        first, extra = self._mlp_args(self._mlp_params(model.f_tran), self._mlp_params(model.g_tran),
+                                      self._mlp_params(model.q1_inv_tran))
         lseW, bwXanc, bwX, bwW, sel, anc, ws = BsimWRFunction.apply(
             desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, filt["Fm"], filt["logW"], filt["lse"],
-            *self._mlp_params(model.f_tran), *self._mlp_params(model.g_tran), *self._mlp_params(model.q1_inv_tran),
-            self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
-            bmu2, minit, self._sigma(self.BSim_q_init), imean, isig)
+            *first, self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv), self._sigma(self.BSim_q2),
+            bmu2, minit, self._sigma(self.BSim_q_init), imean, isig, *extra)
         # ws[-1] (as int32) is nonzero iff an exchange poll of the kernel timed out (check_exchange, the tests)
         self._last_ws = ws
         return {"lseW": lseW, "bwXanc": bwXanc, "bwX": bwX, "bwW": bwW, "sel": sel, "anc": anc, "ws": ws}

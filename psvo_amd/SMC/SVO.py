@@ -81,31 +81,63 @@ class SVO:
         return trans
 
     def _kernel_width(self):
-        """(H the kernels run at, whether any per-particle MLP is narrower than that).
+        """(H the kernels run at, whether any per-particle MLP layer is narrower than that, hidden layers per MLP).
 
-        The kernels take ONE hidden width for all per-particle MLPs of a launch, from _KERNEL_H.  Other widths the flags can
-        reach (q1_layers=50, g_layers=16 beside q1_layers=32, ...) run at the next instantiated width with zero-padded hidden
-        units: a padded unit is relu(x . 0 + 0) = 0 times a zero row of the output kernel, so values and the gradients of the
-        real entries are unchanged (the padding is `torch.nn.functional.pad` on the parameters: autograd slices the padded
-        gradient back).  Wider than 64 has no kernel: ValueError."""
+        The kernels take ONE hidden width and ONE depth (1 or 2 hidden layers: psvo_desc.layers) for all per-particle MLPs
+        of a launch.  Other widths the flags can reach (q1_layers=50, g_layers=16 beside q1_layers=32, "64,32", ...) run at
+        the next instantiated width with zero-padded hidden units: a padded unit is relu(x . 0 + 0) = 0 times a zero row of
+        the next kernel, so values and the gradients of the real entries are unchanged (the padding is
+        `torch.nn.functional.pad` on the parameters: autograd slices the padded gradient back).  Wider than 64 has no
+        kernel, and MLPs of different depth cannot be padded to a common one (an extra relu layer is not the identity):
+        ValueError."""
         cached = self.__dict__.get("_kw")
         if cached is None:
-            widths = [t.hip_params()[0].shape[1] for t in self._particle_mlps()]
-            fit = [H for H in self._KERNEL_H if H >= max(widths)]
+            params = [t.hip_params() for t in self._particle_mlps()]
+            depths = sorted(set(1 if len(p) == 4 else 2 for p in params))
+            if len(depths) != 1:
+                raise ValueError("per-particle MLPs (q1 / f / g / q1_inv) with different numbers of hidden layers %s: the "
+                                 "kernels take one depth per launch; no fallback path exists"
+                                 % [t.Dhs for t in self._particle_mlps()])
+            layers = depths[0]
+            widths = [w for p in params for w in ((p[0].shape[1],) if layers == 1 else (p[0].shape[1], p[4].shape[1]))]
+            avail = self._KERNEL_H if layers == 1 else self._KERNEL_H[1:]      # (two layers: 32 and 64)
+            fit = [H for H in avail if H >= max(widths)]
             if not fit:
                 raise ValueError("per-particle MLP hidden width %d exceeds the widest kernel instantiation (%d); "
                                  "no fallback path exists" % (max(widths), self._KERNEL_H[-1]))
-            cached = self._kw = (fit[0], any(w != fit[0] for w in widths))
+            cached = self._kw = (fit[0], any(w != fit[0] for w in widths), layers)
         return cached
 
     def _mlp_params(self, tran):
-        """(W1, b1, W2, b2) of a per-particle MLP at the kernels' hidden width"""
-        W1, b1, W2, b2 = tran.hip_params()
-        pad = self._kernel_width()[0] - W1.shape[1]
-        if pad:
-            F = torch.nn.functional
-            W1, b1, W2 = F.pad(W1, (0, pad)), F.pad(b1, (0, pad)), F.pad(W2, (0, 0, 0, pad))
-        return W1, b1, W2, b2
+        """(W1, b1, W2, b2[, Wh, bh]) of a per-particle MLP at the kernels' hidden width"""
+        p = tran.hip_params()
+        H = self._kernel_width()[0]
+        F = torch.nn.functional
+        W1, b1, W2, b2 = p[:4]
+        if len(p) == 4:
+            pad = H - W1.shape[1]
+            if pad:
+                W1, b1, W2 = F.pad(W1, (0, pad)), F.pad(b1, (0, pad)), F.pad(W2, (0, 0, 0, pad))
+            return W1, b1, W2, b2
+        Wh, bh = p[4:]
+        p1, p2 = H - W1.shape[1], H - Wh.shape[1]
+        if p1 or p2:
+            W1, b1 = F.pad(W1, (0, p1)), F.pad(b1, (0, p1))
+            Wh, bh = F.pad(Wh, (0, p2, 0, p1)), F.pad(bh, (0, p2))
+            W2 = F.pad(W2, (0, 0, 0, p2))
+        return W1, b1, W2, b2, Wh, bh
+
+    @staticmethod
+    def _mlp_args(*mlps):
+        """positional layout of the autograd nodes: four tensors per MLP (None for an absent one), then -- two hidden
+        layers -- (Wh, bh) per MLP behind everything else.  Returns (first, extra)."""
+        first, extra = [], []
+        two = any(p is not None and len(p) == 6 for p in mlps)
+        for p in mlps:
+            first += list(p[:4]) if p is not None else [None] * 4
+            if two:
+                extra += list(p[4:6]) if p is not None else [None] * 2
+        return first, extra
 
     def _desc(self, M=1):
         d = self._make_desc(M, self._kernel_width()[0])
@@ -129,7 +161,8 @@ class SVO:
         return ops.make_desc(self.batch_size, self.time, self.n_particles, M, self.model.Dx, self.model.Dy, H,
                              resample=self.resample_particles, two_q=self.model.use_2_q,
                              bootstrap=self.model.use_bootstrap,
-                             emission=int(getattr(self.model, "poisson_emission", False)))
+                             emission=int(getattr(self.model, "poisson_emission", False)),
+                             layers=self._kernel_width()[2])
 
     def _randn(self, *shape, device):
         return torch.randn(*shape, device=device, dtype=torch.float32, generator=self.generator)
@@ -183,7 +216,9 @@ class SVO:
         if self.resample_particles and u is None and idx_in is None:
             u = self._rand(T, B, N, device=dev)
 
-        f_params = (None,) * 4 if model.use_bootstrap else self._mlp_params(model.f_tran)
+        first, extra = self._mlp_args(self._mlp_params(model.q1_tran),
+                                      None if model.use_bootstrap else self._mlp_params(model.f_tran),
+                                      self._mlp_params(model.g_tran))
         sig_f = None if model.use_bootstrap else self._sigma(self.f)
         self._m0, self._sig0 = m0, sig0
         desc = self._desc()
@@ -192,8 +227,7 @@ class SVO:
         # one opaque autograd node: psvo_filter_forward / psvo_filter_backward
         lse, Fm, logW, X, Xanc, idx = FilterFunction.apply(
             desc, obs_TB, eps, u, idx_in,
-            *self._mlp_params(model.q1_tran), *f_params, *self._mlp_params(model.g_tran),
-            self._sigma(self.q1), sig_q2, sig_f, self._sigma(self.g), mu2, m0, sig0, fm0, fsig0)
+            *first, self._sigma(self.q1), sig_q2, sig_f, self._sigma(self.g), mu2, m0, sig0, fm0, fsig0, *extra)
         return {"lse": lse, "Fm": Fm, "logW": logW, "X": X, "Xanc": Xanc, "idx": idx, "eps": eps, "u": u}
 
     def compute_log_ZSMC(self, lse):

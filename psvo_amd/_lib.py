@@ -23,11 +23,11 @@ class PsvoHipError(RuntimeError):
 
 class psvo_desc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("B", "T", "N", "M", "Dx", "Dy", "H", "resample", "two_q", "bootstrap", "emission")]
+                ("B", "T", "N", "M", "Dx", "Dy", "H", "resample", "two_q", "bootstrap", "emission", "layers")]
 
 
 class psvo_mlp(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("W1", "b1", "W2", "b2")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("W1", "b1", "W2", "b2", "Wh", "bh")]
 
 
 _P = ctypes.c_void_p
@@ -46,6 +46,9 @@ SIGNATURES = {
     "psvo_mlp_wgrad_blocks": (ctypes.c_int, [ctypes.c_longlong]),
     "psvo_mlp_wgrad": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       _P, _P, _MLP, _P, _P, ctypes.c_int, _P]),
+    "psvo_mlp2_wgrad_blocks": (ctypes.c_int, [ctypes.c_longlong]),
+    "psvo_mlp2_wgrad": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       _P, _P, _MLP, _P, _P, ctypes.c_int, _P]),
     "psvo_bsim_forward": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 22 + [_P]),
     "psvo_bsim_blocks": (ctypes.c_int, [_DESC]),
     "psvo_set_tuning": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

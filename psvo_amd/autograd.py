@@ -110,6 +110,31 @@ def _cg(t):
     return None if t is None else t.contiguous()
 
 
+def _mlps(t, n=3):
+    """the n MLPs of a node's positional tensors: t[0:4n] = (W1, b1, W2, b2) each; with two hidden layers the node
+    receives (Wh, bh) per MLP as 2n extra tensors behind its regular 4n + 9 ones (SVO._mlp_args)."""
+    mlps = [tuple(t[4 * i:4 * i + 4]) for i in range(n)]
+    extra = t[4 * n + 9:]
+    if extra:
+        mlps = [m + tuple(extra[2 * i:2 * i + 2]) if extra[2 * i] is not None else m for i, m in enumerate(mlps)]
+    return mlps
+
+
+def _mlp_grads(r, keys, dims, H, layers, gbufs):
+    """gradients of a node's MLP inputs in its positional layout -> (first 4 per MLP, extras (Wh, bh) per MLP).
+    keys: result-dict entries (None = MLP absent); gbufs[i] not None = accumulated in place by the kernels."""
+    first, extra = (), ()
+    for key, (Din, Dout), gb in zip(keys, dims, gbufs):
+        if key is None or gb is not None:
+            first += (None,) * 4
+            extra += (None,) * 2
+        else:
+            g = ops.split_mlp_grad(r[key], Din, H, Dout, layers)
+            first += tuple(g[:4])
+            extra += tuple(g[4:6]) if layers == 2 else (None, None)
+    return first, (extra if layers == 2 else ())
+
+
 def _used_on(stream, tensors):
     """tensors allocated from another stream's pool are about to be consumed on `stream`"""
     for t in tensors:
@@ -134,7 +159,7 @@ class FilterFunction(torch.autograd.Function):
         # main stream AFTER the event the side-stream reverse pass waits for
         ctx.set_materialize_grads(False)
         t = [_cf(v) for v in t]
-        q1, f, g = tuple(t[0:4]), tuple(t[4:8]), tuple(t[8:12])
+        q1, f, g = _mlps(t)
         sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0 = t[12:21]
         ctx.gbufs = getattr(desc, "_gbufs", None)     # (q1, f, g) flat-gradient slices or None
         if desc.bootstrap:
@@ -225,20 +250,17 @@ class FilterFunction(torch.autograd.Function):
                                     obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm), dlogW=_cg(dlogW),
                                     gbufs=ctx.gbufs)
         Dx, Dy, H = desc.Dx, desc.Dy, desc.H
-        gb = ctx.gbufs or (None, None, None)
-        none4 = (None,) * 4
-        gq1 = none4 if gb[0] is not None else ops.split_mlp_grad(r["gq1"], Dx, H, Dx)
-        gf = none4 if (desc.bootstrap or gb[1] is not None) else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
-        gg = none4 if gb[2] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
+        gfirst, gextra = _mlp_grads(r, ("gq1", None if desc.bootstrap else "gf", "gg"), ((Dx, Dx), (Dx, Dx), (Dx, Dy)), H,
+                                    2 if desc.layers == 2 else 1, ctx.gbufs or (None, None, None))
         two_q, boot = bool(desc.two_q), bool(desc.bootstrap)
         # (one tensor passed as both m0 and fm0 -- the default wiring -- gets the summed gradient in d m0 from the kernel:
         #  returning the zero d fm0 as well would only make the engine launch an add; likewise sig0 / fsig0)
         same_m = m0.data_ptr() == fm0.data_ptr()
         same_s = sig0.data_ptr() == fsig0.data_ptr()
-        return (None, None, None, None, None) + tuple(gq1) + tuple(gf) + tuple(gg) + (
+        return (None, None, None, None, None) + gfirst + (
             r["dsig_q1"], r["dsig_q2"] if two_q else None, None if boot else r["dsig_f"], r["dsig_g"],
             r["dmu2"] if two_q else None, r["dm0"], r["dsig0"], None if same_m else r["dfm0"],
-            None if same_s else r["dfsig0"])
+            None if same_s else r["dfsig0"]) + gextra
 
 
 def _filter_node_of(Fm, ov):
@@ -263,7 +285,7 @@ class BsimFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, desc, obs_TB, eps_b, u_b, sel_in, Fm, logW, lse, *t):
         t = [_cf(v) for v in t]
-        f, g, q = tuple(t[0:4]), tuple(t[4:8]), tuple(t[8:12])
+        f, g, q = _mlps(t)
         sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig = t[12:21]
         filt = {"X": None, "Fm": _cf(Fm), "logW": _cf(logW), "lse": _cf(lse)}
         ov = getattr(desc, "_ov", None)
@@ -317,16 +339,13 @@ class BsimFunction(torch.autograd.Function):
             ov.bsim_wgrad_done = torch.cuda.Event()
             ov.bsim_wgrad_done.record(ws if ws is not None else torch.cuda.current_stream())
         Dx, Dy, H = desc.Dx, desc.Dy, desc.H
-        gb = ctx.gbufs or (None, None, None)
-        none4 = (None,) * 4
-        gf = none4 if gb[0] is not None else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
-        gg = none4 if gb[1] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
-        gq = none4 if gb[2] is not None else ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
+        gfirst, gextra = _mlp_grads(r, ("gf", "gg", "gq1inv"), ((Dx, Dx), (Dx, Dy), (Dx, Dx)), H,
+                                    2 if desc.layers == 2 else 1, ctx.gbufs or (None, None, None))
         dFm, dlogW = r["dFm"], r["dlogW"]
         ops.sum_chain_rows(r, desc.T, desc.B, Dx)       # (one reduction for d bmu2 / d minit / d imean)
-        return (None, None, None, None, None, dFm, dlogW, None) + tuple(gf) + tuple(gg) + tuple(gq) + (
+        return (None, None, None, None, None, dFm, dlogW, None) + gfirst + (
             r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2"],
-            r["dminit"], r["dsig_init"], r["dimean"], r["disig"])
+            r["dminit"], r["dsig_init"], r["dimean"], r["disig"]) + gextra
 
 
 def _note_exchange(desc, ws, bit):
@@ -349,7 +368,7 @@ class BsimWRFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, Fm, logW, lse, *t):
         t = [_cf(v) for v in t]
-        f, g, q = tuple(t[0:4]), tuple(t[4:8]), tuple(t[8:12])
+        f, g, q = _mlps(t)
         sig_f, sig_g, sig_q1inv, sig_bq2, bmu2, minit, sig_init, imean, isig = t[12:21]
         filt = {"Fm": _cf(Fm), "logW": _cf(logW), "lse": _cf(lse)}
         ov = getattr(desc, "_ov", None)
@@ -389,16 +408,13 @@ class BsimWRFunction(torch.autograd.Function):
             ov.bsim_wgrad_done = torch.cuda.Event()
             ov.bsim_wgrad_done.record(ws if ws is not None else torch.cuda.current_stream())
         Dx, Dy, H = desc.Dx, desc.Dy, desc.H
-        gb = ctx.gbufs or (None, None, None)
-        none4 = (None,) * 4
-        gf = none4 if gb[0] is not None else ops.split_mlp_grad(r["gf"], Dx, H, Dx)
-        gg = none4 if gb[1] is not None else ops.split_mlp_grad(r["gg"], Dx, H, Dy)
-        gq = none4 if gb[2] is not None else ops.split_mlp_grad(r["gq1inv"], Dx, H, Dx)
+        gfirst, gextra = _mlp_grads(r, ("gf", "gg", "gq1inv"), ((Dx, Dx), (Dx, Dy), (Dx, Dx)), H,
+                                    2 if desc.layers == 2 else 1, ctx.gbufs or (None, None, None))
         ops.sum_chain_rows(r, desc.T, desc.B, Dx)
         _note_exchange(desc, r["ws"], 2)          # (after the weight-gradient launches: see ops.sum_chain_rows)
-        return (None,) * 7 + (r["dFm"], r["dlogW"], r["dlse"]) + tuple(gf) + tuple(gg) + tuple(gq) + (
+        return (None,) * 7 + (r["dFm"], r["dlogW"], r["dlse"]) + gfirst + (
             r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2"],
-            r["dminit"], r["dsig_init"], r["dimean"], r["disig"])
+            r["dminit"], r["dsig_init"], r["dimean"], r["disig"]) + gextra
 
 
 class RowsMLPFunction(torch.autograd.Function):

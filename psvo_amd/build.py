@@ -11,7 +11,10 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpsvo_hip.so")
 SOURCES = ["api.hip", "filter_fwd.hip", "bsim_fwd.hip", "lstm.hip", "filter_bwd.hip", "mlp_grad.hip", "bsim_bwd.hip", "bsim_bwd_dx2.hip", "bsim_bwd_dx3.hip", "bsim_bwd_dx4.hip", "bsim_bwd2_dx2.hip", "bsim_bwd2_dx3.hip", "bsim_bwd2_dx4.hip",
-           "lstm_bwd.hip", "adam.hip", "psvowr_fwd.hip", "psvowr_bwd.hip", "rows_mlp.hip", "dense.hip"]
+           "lstm_bwd.hip", "adam.hip", "psvowr_fwd.hip", "psvowr_bwd.hip", "rows_mlp.hip", "dense.hip",
+           # two hidden layers per per-particle MLP (psvo_desc.layers == 2): the same sources compiled with PSVO_L = 2
+           "psvowr_bwd_l2.hip", "psvowr_fwd_l2.hip", "bsim_fwd_l2.hip", "bsim_bwd_dx2_l2.hip", "bsim_bwd_dx3_l2.hip",
+           "bsim_bwd_dx4_l2.hip", "filter_bwd_l2.hip", "filter_fwd_l2.hip"]
 HEADERS = ["common.h", "bsim_bwd_impl.h", "bsim_bwd2_impl.h", os.path.join("..", "..", "include", "psvo_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize"]
 
@@ -30,7 +33,12 @@ def build_lib(force=False, verbose=True):
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + hdrs):
+        deps = [src] + hdrs
+        if s.endswith("_l2.hip"):
+            deps.append(os.path.join(CSRC, s.replace("_l2.hip", ".hip")))       # (#include "X.hip")
+        if s.startswith("bsim_bwd_dx"):
+            deps.append(os.path.join(CSRC, s.replace("_l2", "")))
+        if force or _stale(obj, deps):
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
 
     def run(cmd):

@@ -9,6 +9,14 @@ extern template int bb2_dispatch_dy<4>(const BsimBwdArgs&, const BsimBwdOut&, in
 extern template int bb_dispatch_dy<2>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
 extern template int bb_dispatch_dy<3>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
 extern template int bb_dispatch_dy<4>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
+// two hidden layers per MLP (psvo_desc.layers == 2): the v1 kernel family compiled with PSVO_L = 2 (bsim_bwd_dx{2,3,4}_l2.hip)
+namespace l2 {
+template <int DX>
+int bb_dispatch_dy(const BsimBwdArgs& a, const BsimBwdOut& o, int Dy, int H, int M, hipStream_t s);
+extern template int bb_dispatch_dy<2>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
+extern template int bb_dispatch_dy<3>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
+extern template int bb_dispatch_dy<4>(const BsimBwdArgs&, const BsimBwdOut&, int, int, int, hipStream_t);
+}  // namespace l2
 }  // namespace psvo
 
 // Which reverse kernel psvo_bsim_backward launches (psvo_set_tuning(PSVO_TUNE_BSIM_BWD, v)):
@@ -18,7 +26,8 @@ extern template int bb_dispatch_dy<4>(const BsimBwdArgs&, const BsimBwdOut&, int
 //   split into three bf16 pieces (Dx = 2; other Dx run as 1),  -1 = the measured default.  The workspace geometry (psvo_bsim_blocks) follows the choice, so set it before sizing buffers.
 static int g_bsim_bwd_variant = -1;
 
-static int bsim_bwd_variant(int B, int T, int N, int M, int Dx, int Dy) {
+static int bsim_bwd_variant(int B, int T, int N, int M, int Dx, int Dy, int layers = 1) {
+    if (layers == 2) return 0;    // (v2's register budget has no room for a second hidden layer: v1 only)
     // measured default (profiles/r02_bsim_bwd_ab.md): v2 wins where its working set fits the 256 VGPRs
     // of two waves per SIMD -- Dx = 2 (C* -8 %, C4 -29 %) and, with the scalar accumulators in LDS, Dx = 3 (C3 -12 %); at
     // Dx = 4 it still spills 65 registers to scratch and v1 (one wave per SIMD, 512 VGPRs) is faster
@@ -49,7 +58,8 @@ extern "C" int psvo_get_tuning(int key) {
 extern "C" int psvo_bsim_blocks(const psvo_desc* desc) {
     if (!desc) return PSVO_ERR_INVALID;
     int HS, NTB, cpb, nblk;
-    if (bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy) != 0) psvo::bsim2_geometry(desc->N, desc->M, cpb, nblk);
+    if (bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy, desc->layers) != 0)
+        psvo::bsim2_geometry(desc->N, desc->M, cpb, nblk);
     else psvo::bsim_geometry(desc->B, desc->N, desc->M, desc->H, desc->Dx, HS, NTB, cpb, nblk);
     return nblk;
 }
@@ -86,12 +96,21 @@ extern "C" int psvo_bsim_backward(
     a.dimean_rows = dimean_rows; a.sacc_part = sacc_part;
     BsimBwdOut o{};      // (the folds are psvo_bsim_backward_fold's)
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int variant = bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy);
+    const int variant = bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy, desc->layers);
     if (variant != 0) {
         switch (desc->Dx) {
             case 2: return bb2_dispatch_dy<2>(a, o, desc->Dy, desc->H, desc->M, variant - 1, s);
             case 3: return bb2_dispatch_dy<3>(a, o, desc->Dy, desc->H, desc->M, variant - 1, s);
             case 4: return bb2_dispatch_dy<4>(a, o, desc->Dy, desc->H, desc->M, variant - 1, s);
+            default: return PSVO_ERR_UNSUPPORTED;
+        }
+    }
+    if (desc->layers == 2) {
+        if (!f->Wh || !f->bh || !g->Wh || !g->bh || !q1_inv->Wh || !q1_inv->bh) return PSVO_ERR_INVALID;
+        switch (desc->Dx) {
+            case 2: return l2::bb_dispatch_dy<2>(a, o, desc->Dy, desc->H, desc->M, s);
+            case 3: return l2::bb_dispatch_dy<3>(a, o, desc->Dy, desc->H, desc->M, s);
+            case 4: return l2::bb_dispatch_dy<4>(a, o, desc->Dy, desc->H, desc->M, s);
             default: return PSVO_ERR_UNSUPPORTED;
         }
     }

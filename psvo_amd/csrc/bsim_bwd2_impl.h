@@ -142,8 +142,8 @@ __device__ __forceinline__ uint4 bf16x3_b(float v) {
 //   [4 components][4 dwords] + F'_0, F'_1 (20 floats); padded entries use W' = -1e30 (finite: -inf has no bf16 split).
 template <int DX, int DY, int H, int M, int JM>
 __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, 1>;
+    using MG = MlpLds<DX, H, DY, 1>;
     using AC = BAcc<DX, DY>;
     constexpr int PS = (JM == 3) ? 20 : BTileSlot<DX>::kFloats;
     constexpr int FO = (JM == 3) ? 16 : 0;    // F'_0, F'_1 inside a slot (JM >= 2)
@@ -840,8 +840,8 @@ static inline bool bsim2_supported(int B, int T, int N, int M, int Dx, int Dy) {
 
 template <int DX, int DY, int H, int M>
 static int launch_bsim_bwd2(const BsimBwdArgs& a, const BsimBwdOut& o, int jm, hipStream_t stream) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, 1>;
+    using MG = MlpLds<DX, H, DY, 1>;
     const int PS = (jm == 3 && DX == 2) ? 20 : BTileSlot<DX>::kFloats;
     constexpr int UVS = (2 * DX + 3) & ~3;
     int cpb, nblk;

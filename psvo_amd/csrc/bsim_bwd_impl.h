@@ -114,12 +114,13 @@ __device__ __host__ constexpr int stage_bit(int s) {
     return 5;
 }
 
+inline namespace PSVO_LNS {   // l1 / l2: hidden layers of the per-particle MLPs (common.h)
 // HS as in bsim_fwd.hip: HS = 2 spreads a chain over 2*M lanes (half the forward particles and half the
 // hidden units of every MLP per lane) so that small problems still run two waves per SIMD.
 template <int DX, int DY, int H, int M, int CH, int HS>
 __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     using AC = BAcc<DX, DY>;
     constexpr int PS = BTileSlot<DX>::kFloats;
     constexpr bool kRolled = true;
@@ -621,6 +622,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         __syncthreads();
     }
 }
+}  // inline namespace PSVO_LNS
 
 // After the reverse kernel, ONE launch: blocks 0 .. gridDim.x - 2 fold the per-workgroup partials of d Fm / d logW (what the
 // filter's reverse pass waits for) in workgroup order; the last block folds the (B * nblk, NACC) partial sums into the scale
@@ -725,10 +727,11 @@ static inline void bsim_geometry(int B, int N, int M, int H, int Dx, int& HS, in
     nblk = (N + cpb - 1) / cpb;
 }
 
+inline namespace PSVO_LNS {
 template <int DX, int DY, int H, int M>
 static int launch_bsim_bwd(const BsimBwdArgs& a, const BsimBwdOut& o, hipStream_t stream) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     using AC = BAcc<DX, DY>;
     constexpr int PS = BTileSlot<DX>::kFloats;
     int HS, NTB, cpb, nblk;
@@ -771,7 +774,9 @@ static int bb_dispatch_m(const BsimBwdArgs& a, const BsimBwdOut& o, int M, hipSt
 template <int DX, int DY>
 static int bb_dispatch_h(const BsimBwdArgs& a, const BsimBwdOut& o, int H, int M, hipStream_t s) {
     switch (H) {
+#if PSVO_L == 1   // (two hidden layers: widths 32 and 64; narrower ones are zero-padded upstream)
         case 16: return bb_dispatch_m<DX, DY, 16>(a, o, M, s);
+#endif
         case 32: return bb_dispatch_m<DX, DY, 32>(a, o, M, s);
         case 64: return bb_dispatch_m<DX, DY, 64>(a, o, M, s);
         default: return PSVO_ERR_UNSUPPORTED;
@@ -787,6 +792,7 @@ int bb_dispatch_dy(const BsimBwdArgs& a, const BsimBwdOut& o, int Dy, int H, int
         default: return PSVO_ERR_UNSUPPORTED;
     }
 }
+}  // inline namespace PSVO_LNS
 
 }  // namespace psvo
 

@@ -20,6 +20,7 @@
 #include "common.h"
 
 namespace psvo {
+inline namespace PSVO_LNS {   // l1 / l2: hidden layers of the per-particle MLPs (common.h)
 PSVO_TIMERS_DEFINE(bsim_fwd)
 
 
@@ -61,8 +62,8 @@ __device__ __forceinline__ void lse2_merge(float& m, float& s, float m2, float s
 // one VALU op per 4 cycles) this doubles the resident waves per SIMD.
 template <int DX, int DY, int H, int M, int HS>
 __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     constexpr int PS = TileSlot<DX>::kFloats;
     constexpr int kMaxStage = 4;
     constexpr bool kRolled = (2 * MQ::kSize + MG::kSize) > 330;
@@ -463,8 +464,8 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
 
 template <int DX, int DY, int H, int M>
 static int launch_bsim(const BsimArgs& a, hipStream_t stream) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     constexpr int PS = TileSlot<DX>::kFloats;
     // fewer than two waves per SIMD (1024 SIMDs) with one lane per (chain, m): spread each chain over 2M lanes
     const long long waves1 = ((long long)a.B * a.N * M + 63) / 64;
@@ -499,7 +500,9 @@ static int bsim_dispatch_m(const BsimArgs& a, int M, hipStream_t s) {
 template <int DX, int DY>
 static int bsim_dispatch_h(const BsimArgs& a, int H, int M, hipStream_t s) {
     switch (H) {
+#if PSVO_L == 1   // (two hidden layers: widths 32 and 64; narrower ones are zero-padded upstream)
         case 16: return bsim_dispatch_m<DX, DY, 16>(a, M, s);
+#endif
         case 32: return bsim_dispatch_m<DX, DY, 32>(a, M, s);
         case 64: return bsim_dispatch_m<DX, DY, 64>(a, M, s);
         default: return PSVO_ERR_UNSUPPORTED;
@@ -515,9 +518,11 @@ static int bsim_dispatch_dy(const BsimArgs& a, int Dy, int H, int M, hipStream_t
     }
 }
 
+}  // inline namespace PSVO_LNS
 }  // namespace psvo
 
-extern "C" int psvo_bsim_forward(const psvo_desc* desc, const float* X, const float* Fm, const float* logW,
+PSVO_L2_DECL(psvo_bsim_forward)
+PSVO_ENTRY(psvo_bsim_forward)(const psvo_desc* desc, const float* X, const float* Fm, const float* logW,
                                  const float* lse, const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
                                  const float* sig_f, const float* sig_g, const float* sig_q1inv,
                                  const float* sig_bq2, const float* bmu2, const float* minit,
@@ -527,6 +532,13 @@ extern "C" int psvo_bsim_forward(const psvo_desc* desc, const float* X, const fl
                                  float* lam2_all, float* om_all, float* mu1_all,
                                  void* stream) {
     using namespace psvo;
+#if PSVO_L == 1
+    if (desc && desc->layers == 2)
+        return psvo_bsim_forward_l2(desc, X, Fm, logW, lse, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2,
+            minit, sig_init, imean, isig, obs, eps_b, u_b, sel_in, bwX, flp, glp, Omega, sel_out, score, lam2_all,
+            om_all, mu1_all, stream);
+#endif
+    if (!mlp_layers_ok(f) || !mlp_layers_ok(g) || !mlp_layers_ok(q1_inv)) return PSVO_ERR_INVALID;
     if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 ||
         !bmu2 || !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwX || !flp || !glp || !Omega ||
         !sel_out || !score)

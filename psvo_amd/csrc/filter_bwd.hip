@@ -16,6 +16,7 @@
 #include "common.h"
 
 namespace psvo {
+inline namespace PSVO_LNS {   // l1 / l2: hidden layers of the per-particle MLPs (common.h)
 PSVO_TIMERS_DEFINE(filter_bwd)
 
 
@@ -88,11 +89,11 @@ __device__ __forceinline__ float block_sum(float v, float* red, int wave, int la
 
 template <int DX, int DY, int H, int MAXT>
 __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     using AC = FAcc<DX, DY>;
     // one wave per SIMD (<= 256 lanes): let the compiler keep the loop-invariant MLP weights in VGPRs
-    constexpr bool kRolled = (MAXT > 256) || (MlpLds<DX, H, DX>::kSize + MlpLds<DX, H, DY>::kSize > 330);
+    constexpr bool kRolled = (MAXT > 256) || (MlpLds<DX, H, DX, PSVO_L>::kSize + MlpLds<DX, H, DY, PSVO_L>::kSize > 330);
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -394,8 +395,8 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
 // ---------------------------------------------------------------------------------------------
 template <int DX, int DY, int H>
 __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs a) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     using AC = FAcc<DX, DY>;
     constexpr int P = 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -752,8 +753,8 @@ struct FilterBwdOut {
 
 template <int DX, int DY, int H>
 static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipStream_t stream) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     const int NT = (a.N + 63) & ~63;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 4 * DX * NT + 16);
     clear_hip_error();
@@ -785,7 +786,9 @@ static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipS
 template <int DX, int DY>
 static int fb_dispatch_h(const FilterBwdArgs& a, const FilterBwdOut& o, int H, hipStream_t s) {
     switch (H) {
+#if PSVO_L == 1   // (two hidden layers: widths 32 and 64; narrower ones are zero-padded upstream)
         case 16: return launch_filter_bwd<DX, DY, 16>(a, o, s);
+#endif
         case 32: return launch_filter_bwd<DX, DY, 32>(a, o, s);
         case 64: return launch_filter_bwd<DX, DY, 64>(a, o, s);
         default: return PSVO_ERR_UNSUPPORTED;
@@ -801,15 +804,19 @@ static int fb_dispatch_dy(const FilterBwdArgs& a, const FilterBwdOut& o, int Dy,
     }
 }
 
+}  // inline namespace PSVO_LNS
 }  // namespace psvo
 
+#if PSVO_L == 1   // (sizing helpers: independent of the number of hidden layers)
 extern "C" int psvo_filter_acc_size(int Dx, int Dy) { return 10 * Dx + Dy; }
 
 extern "C" long long psvo_filter_ws_floats(int B, int T, int N, int Dx, int Dy) {
     return (long long)B * (10 * Dx + Dy) + (long long)T * B * Dx * N;
 }
+#endif
 
-extern "C" int psvo_filter_backward(
+PSVO_L2_DECL(psvo_filter_backward)
+PSVO_ENTRY(psvo_filter_backward)(
     const psvo_desc* desc, const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g, const float* sig_q1,
     const float* sig_q2, const float* sig_f, const float* sig_g, const float* mu2, const float* m0, const float* sig0,
     const float* fm0, const float* fsig0, const float* obs, const float* eps, const float* X, const float* Fm,
@@ -818,6 +825,13 @@ extern "C" int psvo_filter_backward(
     float* dfm0, float* dsig_q1, float* dsig_q2, float* dsig_f, float* dsig_g, float* dsig0, float* dfsig0,
     float* sacc, void* stream) {
     using namespace psvo;
+#if PSVO_L == 1
+    if (desc && desc->layers == 2)
+        return psvo_filter_backward_l2(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,
+            obs, eps, X, Fm, P1, logW, lse, idx, dlse, nparts, dFm_ext, dlogW_ext, dP, dF, dG, dmu2, dm0, dfm0,
+            dsig_q1, dsig_q2, dsig_f, dsig_g, dsig0, dfsig0, sacc, stream);
+#endif
+    if (!mlp_layers_ok(q1) || !mlp_layers_ok(f) || !mlp_layers_ok(g)) return PSVO_ERR_INVALID;
     if (!desc || !q1 || !g || !sig_q1 || !sig_g || !m0 || !sig0 || !fm0 || !fsig0 || !obs || !eps || !X || !Fm ||
         !logW || !lse || !dP || !dG || !dm0 || !dfm0 || !dsig_q1 || !dsig_q2 || !dsig_f || !dsig_g || !dsig0 ||
         !dfsig0 || !sacc)

@@ -11,6 +11,7 @@
 #include "common.h"
 
 namespace psvo {
+inline namespace PSVO_LNS {   // l1 / l2: hidden layers of the per-particle MLPs (common.h)
 PSVO_TIMERS_DEFINE(filter_fwd)
 
 
@@ -65,8 +66,8 @@ __device__ __forceinline__ StepK<DX> make_stepk(const float* s1, const float* s2
 // (MAXT = 256) keeps every MLP weight in VGPRs only without the extra branch in its time loop, so it is compiled both ways.
 template <int DX, int DY, int H, int MAXT, int EM = 2>
 __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -304,8 +305,8 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_kernel(const FilterArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int DX, int DY, int H, int MAXT>
 __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     constexpr int P = 4;
     constexpr bool kOpaque = false;   // (every instantiated shape keeps its weight slice in VGPRs without scratch)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -558,8 +559,8 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
 
 template <int DX, int DY, int H>
 static int launch_filter(const FilterArgs& a, hipStream_t stream) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     // latency-bound regime (N <= 128: at most 512 lanes, 256 VGPRs each): four lanes per particle.  Only the
     // shapes that compile without scratch use it; the rest keep one lane per particle.
     constexpr bool kLppOk = (H % 16 == 0) && ((H <= 32 && DX <= 3) || H == 16);
@@ -590,7 +591,9 @@ static int launch_filter(const FilterArgs& a, hipStream_t stream) {
 template <int DX, int DY>
 static int dispatch_h(const FilterArgs& a, int H, hipStream_t s) {
     switch (H) {
+#if PSVO_L == 1   // (two hidden layers: widths 32 and 64; narrower ones are zero-padded upstream)
         case 16: return launch_filter<DX, DY, 16>(a, s);
+#endif
         case 32: return launch_filter<DX, DY, 32>(a, s);
         case 64: return launch_filter<DX, DY, 64>(a, s);
         default: return PSVO_ERR_UNSUPPORTED;
@@ -606,15 +609,23 @@ static int dispatch_dy(const FilterArgs& a, int Dy, int H, hipStream_t s) {
     }
 }
 
+}  // inline namespace PSVO_LNS
 }  // namespace psvo
 
-extern "C" int psvo_filter_forward(const psvo_desc* desc, const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
+PSVO_L2_DECL(psvo_filter_forward)
+PSVO_ENTRY(psvo_filter_forward)(const psvo_desc* desc, const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
                                    const float* sig_q1, const float* sig_q2, const float* sig_f,
                                    const float* sig_g, const float* mu2, const float* m0, const float* sig0,
                                    const float* fm0, const float* fsig0, const float* obs, const float* eps,
                                    const float* u, const int32_t* idx_in, float* X, float* Xanc, float* Fm, float* P1,
                                    float* logW, int32_t* idx_out, float* lse, void* stream) {
     using namespace psvo;
+#if PSVO_L == 1
+    if (desc && desc->layers == 2)
+        return psvo_filter_forward_l2(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs,
+            eps, u, idx_in, X, Xanc, Fm, P1, logW, idx_out, lse, stream);
+#endif
+    if (!mlp_layers_ok(q1) || !mlp_layers_ok(f) || !mlp_layers_ok(g)) return PSVO_ERR_INVALID;
     if (!desc || !q1 || !g || !sig_q1 || !sig_g || !m0 || !sig0 || !fm0 || !fsig0 || !obs || !eps || !X ||
         !Xanc || !Fm || !logW || !idx_out || !lse)
         return PSVO_ERR_INVALID;

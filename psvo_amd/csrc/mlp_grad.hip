@@ -155,7 +155,265 @@ static int wgrad_dispatch_out(const WgradArgs& a, int H, int Dout, int nblk, flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two hidden layers (psvo_desc.layers == 2): mu = relu(relu(x W1 + b1) Wh + bh) W2 + b2.
+// Per row the H x H layer costs H^2 FMAs forward, H^2 for d h1 = (d pre2) Wh^T and H^2 for dWh += h1^T (d pre2): three
+// GEMMs with M = rows, N = K = H (and K = rows for the last) -- the one place of the path where the f32 matrix instruction
+// has full tiles.  A workgroup walks chunks of 64 rows:
+//   A (VALU)  h1 = relu(x W1 + b1) -> LDS [64][H]                      thread = (row, quarter of the units)
+//   1 (MFMA)  pre2 = h1 Wh + bh    wave w owns rows 16 w .. 16 w + 15 (v_mfma_f32_16x16x4_f32, operands read from LDS);
+//             in the accumulator layout: h2, d pre2 = [pre2 > 0] (dOut W2^T) -> LDS, dW2 += h2^T dOut, dbh += d pre2
+//   2 (MFMA)  d h1 = (d pre2) Wh^T ; * [h1 > 0] ; dW1 += x^T d h1, db1 += d h1   (accumulator layout, registers)
+//   3 (MFMA)  dWh += h1^T (d pre2)  (K = the 64 rows of the chunk), accumulators persistent over the chunks
+// and writes one partial per workgroup, folded by reduce_partials_kernel (fixed order, no atomics).
+// Output layout (keras order hidden_0, hidden_1, mu_layer): [dW1 (DIN,H) | db1 (H) | dWh (H,H) | dbh (H) | dW2 (H,DOUT) | db2].
+// ---------------------------------------------------------------------------------------------
+typedef float wg_f4 __attribute__((ext_vector_type(4)));
+
+template <int DIN, int DOUT, int H>
+__global__ void __launch_bounds__(256) mlp2_wgrad_kernel(const WgradArgs a) {
+    constexpr int NCT = H / 16;               // 16-wide column tiles of an H-wide matrix
+    constexpr int LDH = H + 1;                // padded LDS row
+    constexpr int TPW = (NCT * NCT) / 4;      // dWh tiles per wave (H = 64: 4, H = 32: 1)
+    static_assert(H == 32 || H == 64, "two-layer weight gradients: H in {32, 64}");
+    constexpr int oB1 = DIN * H, oWh = oB1 + H, oBh = oWh + H * H, oW2 = oBh + H, oB2 = oW2 + H * DOUT, NP2 = oB2 + DOUT;
+    constexpr int NV = DIN + 2 + DOUT;        // per-column sums: dW1 rows, db1, dbh, dW2 columns
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Whs = sm;                 // [H][LDH]
+    float* H1s = Whs + H * LDH;      // [64][LDH]
+    float* D2s = H1s + 64 * LDH;     // [64][LDH]   d pre2
+    float* xs = D2s + 64 * LDH;      // [64][DIN]
+    float* ds = xs + 64 * DIN;       // [64][DOUT]
+    float* w1s = ds + 64 * DOUT;     // W1 [DIN][H] | b1 [H]
+    static_assert((H + 128) * LDH >= 16 * NV * H, "final reduction reuses the tile buffers");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    for (int i = tid; i < H * H; i += 256) Whs[(i / H) * LDH + (i % H)] = a.w.Wh[i];
+    for (int i = tid; i < DIN * H; i += 256) w1s[i] = a.w.W1[i];
+    for (int i = tid; i < H; i += 256) w1s[DIN * H + i] = a.w.b1[i];
+
+    // loop-invariant per lane: columns j = c * 16 + li of W2 and bh
+    float w2r[NCT][DOUT], bhr[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        bhr[c] = a.w.bh[c * 16 + li];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) w2r[c][o] = a.w.W2[(c * 16 + li) * DOUT + o];
+    }
+    wg_f4 accWh[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) accWh[t] = wg_f4{0.f, 0.f, 0.f, 0.f};
+    float gW2[NCT][DOUT], gW1[NCT][DIN], gbh[NCT], gb1[NCT], gb2[DOUT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        gbh[c] = gb1[c] = 0.f;
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) gW2[c][o] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) gW1[c][d] = 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) gb2[o] = 0.f;
+    __syncthreads();
+
+    const long long R = a.S * a.L;
+    const long long nchunk = (R + 63) / 64;
+    for (long long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+        // ---- A: rows of the chunk, first layer ---------------------------------------------------
+        {
+            const long long r = ch * 64 + lane;
+            const bool in = r < R;
+            const long long sg = in ? r / a.L : 0;
+            const int l = in ? (int)(r - sg * a.L) : 0;
+            float x[DIN];
+#pragma unroll
+            for (int d = 0; d < DIN; ++d) x[d] = in ? a.X[(sg * DIN + d) * a.L + l] : 0.f;
+            if (wave == 0) {
+#pragma unroll
+                for (int d = 0; d < DIN; ++d) xs[lane * DIN + d] = x[d];
+#pragma unroll
+                for (int o = 0; o < DOUT; ++o) {
+                    const float g = in ? a.dOut[(sg * DOUT + o) * a.L + l] : 0.f;   // (rows past the end contribute nothing)
+                    ds[lane * DOUT + o] = g;
+                    gb2[o] += g;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < H / 4; ++kk) {
+                const int k = wave * (H / 4) + kk;
+                float pre = w1s[DIN * H + k];
+#pragma unroll
+                for (int d = 0; d < DIN; ++d) pre = fmaf(x[d], w1s[d * H + k], pre);
+                H1s[lane * LDH + k] = fmaxf(pre, 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- 1: pre2 = h1 Wh + bh for rows 16 wave .. + 15 ----------------------------------------
+        wg_f4 acc[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[c] = wg_f4{bhr[c], bhr[c], bhr[c], bhr[c]};
+#pragma unroll 4
+        for (int k0 = 0; k0 < H; k0 += 4) {
+            const float av = H1s[(wave * 16 + li) * LDH + k0 + lg];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float bv = Whs[(k0 + lg) * LDH + c * 16 + li];
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
+            }
+        }
+        // accumulator layout: row i = 16 wave + 4 lg + r, column j = 16 c + li
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = wave * 16 + 4 * lg + r;
+            float dout[DOUT];
+#pragma unroll
+            for (int o = 0; o < DOUT; ++o) dout[o] = ds[i * DOUT + o];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float pre2 = acc[c][r];
+                const float h2 = fmaxf(pre2, 0.f);
+                float dp = 0.f;
+#pragma unroll
+                for (int o = 0; o < DOUT; ++o) {
+                    dp = fmaf(dout[o], w2r[c][o], dp);
+                    gW2[c][o] = fmaf(h2, dout[o], gW2[c][o]);
+                }
+                dp = pre2 > 0.f ? dp : 0.f;
+                gbh[c] += dp;
+                D2s[i * LDH + c * 16 + li] = dp;
+            }
+        }
+        // (rows 16 wave .. + 15 of D2s are this wave's own: no workgroup barrier before step 2)
+        // ---- 2: d h1 = (d pre2) Wh^T, masked; dW1, db1 -----------------------------------------------
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[c] = wg_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k0 = 0; k0 < H; k0 += 4) {
+            const float av = D2s[(wave * 16 + li) * LDH + k0 + lg];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float bv = Whs[(c * 16 + li) * LDH + k0 + lg];     // B[k][j] = Wh[j][k]
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[c], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = wave * 16 + 4 * lg + r;
+            float x[DIN];
+#pragma unroll
+            for (int d = 0; d < DIN; ++d) x[d] = xs[i * DIN + d];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float dh = H1s[i * LDH + c * 16 + li] > 0.f ? acc[c][r] : 0.f;
+                gb1[c] += dh;
+#pragma unroll
+                for (int d = 0; d < DIN; ++d) gW1[c][d] = fmaf(x[d], dh, gW1[c][d]);
+            }
+        }
+        __syncthreads();
+        // ---- 3: dWh += h1^T (d pre2) over the 64 rows ------------------------------------------------
+#pragma unroll 4
+        for (int k0 = 0; k0 < 64; k0 += 4) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tl = wave * TPW + t, rt = tl / NCT, ct = tl % NCT;
+                const float av = H1s[(k0 + lg) * LDH + rt * 16 + li];     // A[i][k] = h1[row k][unit i]
+                const float bv = D2s[(k0 + lg) * LDH + ct * 16 + li];
+                accWh[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accWh[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- the workgroup's partial ------------------------------------------------------------------
+    float* dst = a.partial + (size_t)blockIdx.x * NP2;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tl = wave * TPW + t, rt = tl / NCT, ct = tl % NCT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[oWh + (rt * 16 + 4 * lg + r) * H + ct * 16 + li] = accWh[t][r];
+    }
+    float* red = sm;     // [16 groups][NV][H]: every column sum exists once per (wave, lane group)
+    const int grp = wave * 4 + lg;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int j = c * 16 + li;
+        float* rg = red + (size_t)grp * NV * H;
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) rg[d * H + j] = gW1[c][d];
+        rg[DIN * H + j] = gb1[c];
+        rg[(DIN + 1) * H + j] = gbh[c];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) rg[(DIN + 2 + o) * H + j] = gW2[c][o];
+    }
+    __syncthreads();
+    for (int p = tid; p < NV * H; p += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) v += red[(size_t)g * NV * H + p];
+        const int row = p / H, j = p - row * H;
+        if (row < DIN) dst[row * H + j] = v;
+        else if (row == DIN) dst[oB1 + j] = v;
+        else if (row == DIN + 1) dst[oBh + j] = v;
+        else dst[oW2 + j * DOUT + (row - DIN - 2)] = v;
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) {
+            const float v = wave_sum(gb2[o]);
+            if (lane == 0) dst[oB2 + o] = v;
+        }
+    }
+}
+
+template <int DIN, int DOUT>
+static int launch_wgrad2(const WgradArgs& a, int H, int nblk, float* out, int accumulate, hipStream_t s) {
+    const int NP2 = DIN * H + H + H * H + H + H * DOUT + DOUT;
+    const size_t lds = sizeof(float) * ((size_t)(H + 128) * (H + 1) + 64 * (DIN + DOUT) + (DIN + 1) * H);
+    clear_hip_error();
+    if (H == 32) hipLaunchKernelGGL((mlp2_wgrad_kernel<DIN, DOUT, 32>), dim3(nblk), dim3(256), lds, s, a);
+    else if (H == 64) hipLaunchKernelGGL((mlp2_wgrad_kernel<DIN, DOUT, 64>), dim3(nblk), dim3(256), lds, s, a);
+    else return PSVO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(NP2), dim3(64), 0, s, a.partial, nblk, NP2, out, accumulate);
+    return launch_status();
+}
+
+template <int DIN>
+static int wgrad2_dispatch_out(const WgradArgs& a, int H, int Dout, int nblk, float* out, int acc, hipStream_t s) {
+    switch (Dout) {
+        case 1: return launch_wgrad2<DIN, 1>(a, H, nblk, out, acc, s);
+        case 2: return launch_wgrad2<DIN, 2>(a, H, nblk, out, acc, s);
+        case 3: return launch_wgrad2<DIN, 3>(a, H, nblk, out, acc, s);
+        case 4: return launch_wgrad2<DIN, 4>(a, H, nblk, out, acc, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
+
 }  // namespace psvo
+
+extern "C" int psvo_mlp2_wgrad_blocks(long long rows) {
+    long long nb = (rows + 64 * 4 - 1) / (64 * 4);   // >= 4 chunks of 64 rows per workgroup amortise the final reduction
+    if (nb < 1) nb = 1;
+    if (nb > 768) nb = 768;                          // three workgroups per CU (50 KB of LDS each at H = 64)
+    return (int)nb;
+}
+
+extern "C" int psvo_mlp2_wgrad(long long S, int L, int Din, int H, int Dout, const float* X, const float* dOut,
+                               const psvo_mlp* w, float* partial, float* grad, int accumulate, void* stream) {
+    using namespace psvo;
+    if (!X || !dOut || !w || !w->Wh || !w->bh || !partial || !grad || S <= 0 || L <= 0) return PSVO_ERR_INVALID;
+    WgradArgs a{S, L, X, dOut, *w, partial};
+    const int nblk = psvo_mlp2_wgrad_blocks(S * L);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (Din) {
+        case 1: return wgrad2_dispatch_out<1>(a, H, Dout, nblk, grad, accumulate, s);
+        case 2: return wgrad2_dispatch_out<2>(a, H, Dout, nblk, grad, accumulate, s);
+        case 3: return wgrad2_dispatch_out<3>(a, H, Dout, nblk, grad, accumulate, s);
+        case 4: return wgrad2_dispatch_out<4>(a, H, Dout, nblk, grad, accumulate, s);
+        default: return PSVO_ERR_UNSUPPORTED;
+    }
+}
 
 extern "C" int psvo_mlp_wgrad_blocks(long long rows) {
     long long nb = (rows + 256 * 8 - 1) / (256 * 8);  // >= 8 rows per lane amortise the final reduction

@@ -16,6 +16,7 @@
 #include "common.h"
 
 namespace psvo {
+inline namespace PSVO_LNS {   // l1 / l2: hidden layers of the per-particle MLPs (common.h)
 
 PSVO_TIMERS_DEFINE(psvowr_bwd)
 
@@ -107,8 +108,8 @@ __device__ __forceinline__ void wb_rs_stage(float (&A)[CH][NA], int bit) {
 // MAXT = 256: one wave per SIMD, so up to 512 VGPRs -- no scratch for Dx >= 3 and room to unroll the small MLPs.
 template <int DX, int DY, int H, int M, int MAXT>
 __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     using AC = WAcc<DX, DY>;
     constexpr int PS = WbSlot<DX>::kFloats;
     constexpr bool kRolled = (MAXT > 256) || (H > 32) || (DX > 2);   // small MLPs: unrolled, their LDS reads overlap
@@ -697,8 +698,8 @@ struct WrBwdOut {
 
 template <int DX, int DY, int H, int M>
 static int launch_wr_bwd(const WrBwdArgs& a, const WrBwdOut& o, hipStream_t stream) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     constexpr int PS = WbSlot<DX>::kFloats;
     constexpr int CH = (DX <= 2) ? 16 : 8;         // (as in the kernel)
     const int NP = ((a.N + 4 * CH - 1) / (4 * CH)) * (4 * CH);
@@ -746,7 +747,9 @@ static int wb_dispatch_m(const WrBwdArgs& a, const WrBwdOut& o, int M, hipStream
 template <int DX, int DY>
 static int wb_dispatch_h(const WrBwdArgs& a, const WrBwdOut& o, int H, int M, hipStream_t s) {
     switch (H) {
+#if PSVO_L == 1   // (two hidden layers: widths 32 and 64; narrower ones are zero-padded upstream)
         case 16: return wb_dispatch_m<DX, DY, 16>(a, o, M, s);
+#endif
         case 32: return wb_dispatch_m<DX, DY, 32>(a, o, M, s);
         case 64: return wb_dispatch_m<DX, DY, 64>(a, o, M, s);
         default: return PSVO_ERR_UNSUPPORTED;
@@ -762,14 +765,18 @@ static int wb_dispatch_dy(const WrBwdArgs& a, const WrBwdOut& o, int Dy, int H, 
     }
 }
 
+}  // inline namespace PSVO_LNS
 }  // namespace psvo
 
+#if PSVO_L == 1   // (sizing helpers: independent of the number of hidden layers)
 extern "C" long long psvo_bsimwr_bwd_ws_floats(int B, int T, int N, int Dx) {
     (void)Dx;
     return psvo::wb_ws_floats(B, T, N);
 }
+#endif
 
-extern "C" int psvo_bsimwr_backward(
+PSVO_L2_DECL(psvo_bsimwr_backward)
+PSVO_ENTRY(psvo_bsimwr_backward)(
     const psvo_desc* desc, const float* Fm, const float* logW, const float* lse, const psvo_mlp* f, const psvo_mlp* g,
     const psvo_mlp* q1_inv, const float* sig_f, const float* sig_g, const float* sig_q1inv, const float* sig_bq2,
     const float* bmu2, const float* minit, const float* sig_init, const float* imean, const float* isig,
@@ -779,6 +786,14 @@ extern "C" int psvo_bsimwr_backward(
     float* dminit_rows, float* dimean_rows, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2,
     float* dsig_init, float* disig, float* sacc, float* ws, void* stream) {
     using namespace psvo;
+#if PSVO_L == 1
+    if (desc && desc->layers == 2)
+        return psvo_bsimwr_backward_l2(desc, Fm, logW, lse, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2,
+            minit, sig_init, imean, isig, obs, eps_b, bwXanc, bwW, lseW, sel, anc, lam2_all, om_all, mu1_all,
+            dlseW, xt, dFt, dGt, dmu1, dFm_part, dlogW_part, dlse_part, dbmu2_rows, dminit_rows, dimean_rows,
+            dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig, sacc, ws, stream);
+#endif
+    if (!mlp_layers_ok(f) || !mlp_layers_ok(g) || !mlp_layers_ok(q1_inv)) return PSVO_ERR_INVALID;
     if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 || !bmu2 ||
         !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwXanc || !bwW || !lseW || !sel || !anc ||
         !lam2_all || !om_all || !mu1_all || !dlseW || !xt || !dFt || !dGt || !dmu1 || !dFm_part || !dlogW_part ||

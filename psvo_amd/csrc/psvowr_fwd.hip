@@ -18,6 +18,7 @@
 #include "common.h"
 
 namespace psvo {
+inline namespace PSVO_LNS {   // l1 / l2: hidden layers of the per-particle MLPs (common.h)
 
 struct WrArgs {
     int B, T, N, emission;
@@ -66,8 +67,8 @@ __device__ __forceinline__ void wr_read_slot(const float* p, float (&F)[DX], flo
 
 template <int DX, int DY, int H, int M, int MAXT>
 __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     constexpr int PS = WrSlot<DX>::kFloats;
     constexpr bool kRolled = true;
     constexpr int JB = (MAXT > 256) ? 4 : 16;      // pair-loop block (entries held in registers; 128 VGPRs at 1024 lanes)
@@ -492,8 +493,8 @@ __global__ void __launch_bounds__(MAXT) psvowr_fwd_kernel(const WrArgs a) {
 
 template <int DX, int DY, int H, int M>
 static int launch_wr_fwd(const WrArgs& a, hipStream_t stream) {
-    using MQ = MlpLds<DX, H, DX>;
-    using MG = MlpLds<DX, H, DY>;
+    using MQ = MlpLds<DX, H, DX, PSVO_L>;
+    using MG = MlpLds<DX, H, DY, PSVO_L>;
     constexpr int PS = WrSlot<DX>::kFloats;
     const int K = wr_cluster(a.B, a.N, M);
     const int Nc = (a.N + K - 1) / K;
@@ -545,7 +546,9 @@ static int wr_dispatch_m(const WrArgs& a, int M, hipStream_t s) {
 template <int DX, int DY>
 static int wr_dispatch_h(const WrArgs& a, int H, int M, hipStream_t s) {
     switch (H) {
+#if PSVO_L == 1   // (two hidden layers: widths 32 and 64; narrower ones are zero-padded upstream)
         case 16: return wr_dispatch_m<DX, DY, 16>(a, M, s);
+#endif
         case 32: return wr_dispatch_m<DX, DY, 32>(a, M, s);
         case 64: return wr_dispatch_m<DX, DY, 64>(a, M, s);
         default: return PSVO_ERR_UNSUPPORTED;
@@ -561,16 +564,20 @@ static int wr_dispatch_dy(const WrArgs& a, int Dy, int H, int M, hipStream_t s) 
     }
 }
 
+}  // inline namespace PSVO_LNS
 }  // namespace psvo
 
+#if PSVO_L == 1   // (sizing helpers: independent of the number of hidden layers)
 extern "C" int psvo_bsimwr_blocks(int B, int N, int M) { return psvo::wr_cluster(B, N, M); }
 
 extern "C" long long psvo_bsimwr_ws_floats(int B, int T, int N) {
     (void)T;
     return psvo::wr_ws_floats(B, N);
 }
+#endif
 
-extern "C" int psvo_bsimwr_forward(const psvo_desc* desc, const float* Fm, const float* logW, const float* lse,
+PSVO_L2_DECL(psvo_bsimwr_forward)
+PSVO_ENTRY(psvo_bsimwr_forward)(const psvo_desc* desc, const float* Fm, const float* logW, const float* lse,
                                    const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv, const float* sig_f,
                                    const float* sig_g, const float* sig_q1inv, const float* sig_bq2, const float* bmu2,
                                    const float* minit, const float* sig_init, const float* imean, const float* isig,
@@ -579,6 +586,13 @@ extern "C" int psvo_bsimwr_forward(const psvo_desc* desc, const float* Fm, const
                                    float* lseW, int32_t* sel_out, int32_t* anc_out, float* lam2_all, float* om_all,
                                    float* mu1_all, float* ws, void* stream) {
     using namespace psvo;
+#if PSVO_L == 1
+    if (desc && desc->layers == 2)
+        return psvo_bsimwr_forward_l2(desc, Fm, logW, lse, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2,
+            minit, sig_init, imean, isig, obs, eps_b, u_b, u_r, sel_in, anc_in, bwX, bwXanc, bwW, lseW, sel_out,
+            anc_out, lam2_all, om_all, mu1_all, ws, stream);
+#endif
+    if (!mlp_layers_ok(f) || !mlp_layers_ok(g) || !mlp_layers_ok(q1_inv)) return PSVO_ERR_INVALID;
     if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 || !bmu2 ||
         !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwX || !bwXanc || !bwW || !lseW || !sel_out ||
         !anc_out || !ws)

@@ -18,7 +18,9 @@ def init(backend=None, device=None):
     MASTER_ADDR, MASTER_PORT).  Returns (rank, world_size).  A single process needs no group."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # PSVO_FORCE_PG=1: create the group (and issue the collectives) even for one rank -- the only way to drive RCCL's
+    # initialisation and the all-reduce call path on a one-GPU box
+    if (world > 1 or _forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -26,6 +28,14 @@ def init(backend=None, device=None):
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
+
+
+def _forced():
+    return os.environ.get("PSVO_FORCE_PG", "0") == "1"
+
+
+def _active():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
 
 
 def world_size():
@@ -48,14 +58,14 @@ def shard(n_items, r=None, w=None):
 
 def all_reduce_sum_(flat):
     """The single gradient collective of a training step (in place)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
 def all_reduce_mean_scalar(x):
     """Mean over ranks of a scalar tensor (validation / logged ELBO)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         x = x.detach().clone()
         dist.all_reduce(x, op=dist.ReduceOp.SUM)
         x = x / dist.get_world_size()
@@ -64,14 +74,14 @@ def all_reduce_mean_scalar(x):
 
 def broadcast_(flat, src=0):
     """Make every replica start from rank `src`'s parameters."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.broadcast(flat, src=src)
     return flat
 
 
 def replicas_in_sync(flat):
     """Cheap periodic check that replicas are bit-identical: max |theta - theta_rank0| == 0."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _active():
         return True
     ref = flat.detach().clone()
     dist.broadcast(ref, src=0)

@@ -85,23 +85,35 @@ def _chk(t, shape, name, dtype=torch.float32):
 
 
 def _mlp_struct(p, Din, H, Dout, name):
-    """p = (W1 (Din,H), b1 (H), W2 (H,Dout), b2 (Dout)) keras-layout tensors."""
-    W1, b1, W2, b2 = p
+    """p = (W1 (Din,H), b1 (H), W2 (H,Dout), b2 (Dout)) keras-layout tensors; with two hidden layers
+    (W1, b1, W2, b2, Wh (H,H), bh (H)): hidden_0, mu_layer, hidden_1."""
+    W1, b1, W2, b2 = p[:4]
     _chk(W1, (Din, H), name + ".W1")
     _chk(b1, (H,), name + ".b1")
     _chk(W2, (H, Dout), name + ".W2")
     _chk(b2, (Dout,), name + ".b2")
     s = _lib.psvo_mlp()
+    if len(p) == 6:
+        _chk(p[4], (H, H), name + ".Wh")
+        _chk(p[5], (H,), name + ".bh")
+        s.Wh, s.bh = p[4].data_ptr(), p[5].data_ptr()
+    elif len(p) != 4:
+        raise ValueError("%s: an MLP is 4 tensors (one hidden layer) or 6 (two), got %d" % (name, len(p)))
     if _LAUNCH_STREAM is not None:
-        for t in (W1, b1, W2, b2):
+        for t in p:
             t.record_stream(_LAUNCH_STREAM)
     s.W1, s.b1, s.W2, s.b2 = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
     return s
 
 
-def make_desc(B, T, N, M, Dx, Dy, H, resample=True, two_q=True, bootstrap=True, emission=0):
+def mlp_grad_size(Din, H, Dout, layers=1):
+    return Din * H + H + H * Dout + Dout + (H * H + H if layers == 2 else 0)
+
+
+def make_desc(B, T, N, M, Dx, Dy, H, resample=True, two_q=True, bootstrap=True, emission=0, layers=1):
     d = _lib.psvo_desc()
     d.B, d.T, d.N, d.M, d.Dx, d.Dy, d.H = B, T, N, M, Dx, Dy, H
+    d.layers = int(layers)            # hidden layers of every per-particle MLP of the call (1 or 2)
     d.resample, d.two_q, d.bootstrap = int(resample), int(two_q), int(bootstrap)
     d.emission = int(emission)        # 1: tf_poisson emission (unit-scale normal, softplus mean)
     return d
@@ -267,7 +279,8 @@ def bilstm_forward(x, W_fw, b_fw, W_bw, b_bw, save=False):
 
 
 def mlp_wgrad(X, dOut, w, Din, H, Dout, grad=None, axis=2):
-    """psvo_mlp_wgrad: rows X [S][Din][L], dOut [S][Dout][L] -> flat grad [dW1|db1|dW2|db2].
+    """psvo_mlp_wgrad / psvo_mlp2_wgrad: rows X [S][Din][L], dOut [S][Dout][L] -> flat grad [dW1|db1|dW2|db2]
+    (two hidden layers, len(w) == 6: [dW1|db1|dWh|dbh|dW2|db2], the H x H products on the f32 matrix instruction).
     X / dOut are contiguous tensors whose feature axis is `axis` (dims before it flatten to the
     segments S, dims after it to the rows L of a segment), e.g. (T,B,Din,N) or (T,B,Din,N,M)."""
     lib = _lib.load()
@@ -284,17 +297,21 @@ def mlp_wgrad(X, dOut, w, Din, H, Dout, grad=None, axis=2):
     for v in X.shape[ax + 1:]:
         L *= v
     ws = _mlp_struct(w, Din, H, Dout, "w")
-    NP = Din * H + H + H * Dout + Dout
-    nblk = lib.psvo_mlp_wgrad_blocks(S * L)
+    two = len(w) == 6
+    name = "psvo_mlp2_wgrad" if two else "psvo_mlp_wgrad"
+    NP = mlp_grad_size(Din, H, Dout, 2 if two else 1)
+    nblk = (lib.psvo_mlp2_wgrad_blocks if two else lib.psvo_mlp_wgrad_blocks)(S * L)
     partial = _empty(nblk, NP, device=dev)
     acc = grad is not None
     if grad is None:
         grad = _empty(NP, device=dev)
-    _mark("psvo_mlp_wgrad", 0)
-    st = lib.psvo_mlp_wgrad(S, L, Din, H, Dout, _ptr(X), _ptr(dOut), ctypes.byref(ws), _ptr(partial), _ptr(grad),
+    elif grad.numel() != NP:
+        raise ValueError("mlp_wgrad: gradient slice of %d floats for an MLP of %d parameters" % (grad.numel(), NP))
+    _mark(name, 0)
+    st = getattr(lib, name)(S, L, Din, H, Dout, _ptr(X), _ptr(dOut), ctypes.byref(ws), _ptr(partial), _ptr(grad),
                             int(acc), _stream())
-    _mark("psvo_mlp_wgrad", 1)
-    _lib.check(st, "psvo_mlp_wgrad")
+    _mark(name, 1)
+    _lib.check(st, name)
     return grad
 
 
@@ -367,9 +384,14 @@ def dense_backward(X, Y, dY, W, relu, need_dX=True):
     return dX, grad[:Din * Dout].view(Din, Dout), grad[Din * Dout:]
 
 
-def split_mlp_grad(g, Din, H, Dout):
-    """flat [dW1|db1|dW2|db2] -> (dW1 (Din,H), db1 (H), dW2 (H,Dout), db2 (Dout)) views."""
+def split_mlp_grad(g, Din, H, Dout, layers=1):
+    """flat [dW1|db1|dW2|db2] -> (dW1 (Din,H), db1 (H), dW2 (H,Dout), db2 (Dout)) views; two hidden layers: flat
+    [dW1|db1|dWh|dbh|dW2|db2] -> (dW1, db1, dW2, db2, dWh (H,H), dbh (H)), the order of the 6-tensor MLP tuples."""
     a = Din * H
+    if layers == 2:
+        b = a + H + H * H + H
+        return (g[:a].view(Din, H), g[a:a + H], g[b:b + H * Dout].view(H, Dout), g[b + H * Dout:],
+                g[a + H:a + H + H * H].view(H, H), g[a + H + H * H:b])
     return (g[:a].view(Din, H), g[a:a + H], g[a + H:a + H + H * Dout].view(H, Dout), g[a + H + H * Dout:])
 
 

@@ -25,8 +25,8 @@ class FlatParams(object):
                 seen.add(id(q))
                 self.params.append(q)
         for mod in module.modules():
-            if isinstance(mod, MLP_transformation) and len(mod.Dhs) == 1:
-                for q in (mod.kernels[0], mod.biases[0], mod.mu_kernel, mod.mu_bias):
+            if isinstance(mod, MLP_transformation) and len(mod.Dhs) in (1, 2):
+                for q in self._mlp_order(mod):
                     add(q)
         for q in module.parameters():
             add(q)
@@ -44,10 +44,19 @@ class FlatParams(object):
         self.numel = n
         self._annotate(module)
 
+    @staticmethod
+    def _mlp_order(mod):
+        """[W1 | b1 | W2 | b2] (psvo_mlp_wgrad) or, two hidden layers, [W1 | b1 | Wh | bh | W2 | b2] (psvo_mlp2_wgrad)"""
+        ps = []
+        for W, b in zip(mod.kernels, mod.biases):
+            ps += [W, b]
+        return ps + [mod.mu_kernel, mod.mu_bias]
+
     def _annotate(self, module):
         """Tell the native backward passes where each module's gradient lives in the flat buffer so they can
         accumulate into it directly (one launch) instead of returning tensors for autograd to add one by one:
-          * one-hidden-layer MLP_transformation: [W1 | b1 | W2 | b2] -- exactly psvo_mlp_wgrad's layout;
+          * MLP_transformation with one hidden layer: [W1 | b1 | W2 | b2] -- exactly psvo_mlp_wgrad's layout; with two:
+            [W1 | b1 | Wh | bh | W2 | b2] -- psvo_mlp2_wgrad's;
           * LSTMBlockCellLayer: [kernel | bias];
           * all tf_mvn.sigma_con vectors, when contiguous: one fused softplus/clamp for every distribution."""
         from .distribution.mvn import tf_mvn
@@ -71,8 +80,8 @@ class FlatParams(object):
 
         for mod in module.modules():
             mod.__dict__.pop("_flat_grad", None)
-            if isinstance(mod, MLP_transformation) and len(mod.Dhs) == 1:
-                b = block([mod.kernels[0], mod.biases[0], mod.mu_kernel, mod.mu_bias])
+            if isinstance(mod, MLP_transformation) and len(mod.Dhs) in (1, 2):
+                b = block(self._mlp_order(mod))
             elif isinstance(mod, LSTMBlockCellLayer):
                 b = block([mod.kernel, mod.bias])
             else:

@@ -95,11 +95,16 @@ class MLP_transformation(nn.Module):
         return mu, None
 
     def hip_params(self):
-        """(W1, b1, W2, b2) for the fused kernels: exactly one hidden layer."""
-        if len(self.Dhs) != 1:
-            raise ValueError("%s: the fused HIP kernels take one hidden layer per particle MLP, got %s "
-                             "(no fallback path exists)" % (self.name, self.Dhs))
-        return (self.kernels[0], self.biases[0], self.mu_kernel, self.mu_bias)
+        """the per-particle form the persistent kernels take: (W1, b1, W2, b2) for one hidden layer,
+        (W1, b1, W2, b2, Wh, bh) for two (hidden_0, mu_layer, then hidden_1: psvo_mlp in include/psvo_hip.h)."""
+        if len(self.Dhs) not in (1, 2) or self.use_residual:
+            raise ValueError("%s: the fused HIP kernels take one or two hidden layers per particle MLP and no residual "
+                             "connection, got layers %s, use_residual=%s (no fallback path exists)"
+                             % (self.name, self.Dhs, self.use_residual))
+        p = (self.kernels[0], self.biases[0], self.mu_kernel, self.mu_bias)
+        if len(self.Dhs) == 2:
+            p = p + (self.kernels[1], self.biases[1])
+        return p
 
     def get_variables(self):
         """reference MLP.py:70-86."""

@@ -30,7 +30,7 @@ def test_header_symbols_are_exported_and_bound(built_lib):
 def test_version_and_status_strings(built_lib):
     from psvo_amd import _lib
     lib = _lib.load()
-    assert lib.psvo_abi_version() == 3
+    assert lib.psvo_abi_version() == 4      # (4: psvo_desc.layers, psvo_mlp.Wh / bh, psvo_mlp2_wgrad)
     assert lib.psvo_status_string(0) == b"ok"
     assert b"unsupported" in lib.psvo_status_string(_lib.PSVO_ERR_UNSUPPORTED)
     assert lib.psvo_filter_acc_size(2, 1) == 21 and lib.psvo_bsim_acc_size(3, 2) == 23

@@ -149,14 +149,16 @@ def test_trainer_improves_elbo(built_lib, tmp_path, monkeypatch, objective, hipg
     assert (len(graphs) == 1 and all(g is not False for g in graphs.values())) if hipgraph == "1" else not graphs
 
 
-@pytest.mark.parametrize("obj", ["PSVO", "SVO"])
-def test_flat_buffer_gradients_match_autograd_path(built_lib, obj):
+@pytest.mark.parametrize("obj,layers", [("PSVO", "32"), ("SVO", "32"), ("PSVO", "32,32"), ("SVO", "64,64")])
+def test_flat_buffer_gradients_match_autograd_path(built_lib, obj, layers):
     """with optim.FlatParams the native backward passes accumulate straight into the flat gradient buffer
-    (and all sigmas come from one fused launch): same gradients as the plain autograd path"""
+    (and all sigmas come from one fused launch): same gradients as the plain autograd path -- one hidden layer per
+    particle MLP ([W1|b1|W2|b2] slices) and two ([W1|b1|Wh|bh|W2|b2], psvo_mlp2_wgrad)"""
     from psvo_amd.model import SSM
     from psvo_amd.optim import FlatParams
     FLAGS = Hh.make_flags(obj, n_particles=32, n_particles_for_BSim_proposal=8, batch_size=3, time=9,
-                          y_smoother_Dhs="8", X0_smoother_Dhs="8", use_bootstrap=(obj == "PSVO"))
+                          y_smoother_Dhs="8", X0_smoother_Dhs="8", use_bootstrap=(obj == "PSVO"),
+                          q1_layers=layers, f_layers=layers, g_layers=layers)
     torch.manual_seed(0)
     m1 = Hh.perturb_(SSM(FLAGS)).cuda()
     m2 = SSM(FLAGS).cuda()
@@ -182,6 +184,45 @@ def test_flat_buffer_gradients_match_autograd_path(built_lib, obj):
     for n, g in outs[0][1].items():
         g2 = outs[1][1][n]
         assert torch.allclose(g, g2, atol=2e-5 + 1e-4 * float(g.abs().max()), rtol=1e-3), n
+
+
+@pytest.mark.parametrize("shape,Din,H,Dout", [((3, 2, 2, 50, 4), 2, 32, 2), ((7, 3, 3, 130), 3, 64, 1), ((2, 5, 4, 9, 8), 4, 64, 4),
+                                             ((40, 2, 2, 64, 16), 2, 64, 2), ((1, 1, 2, 5), 2, 32, 3)])
+def test_mlp2_wgrad_matches_torch(built_lib, shape, Din, H, Dout):
+    """psvo_mlp2_wgrad (two hidden layers; the H x H products on v_mfma_f32_16x16x4_f32) against torch autograd of the same
+    MLP in fp64 over the same rows: every parameter gradient rel 1e-4 of its largest entry; ragged row counts (not a
+    multiple of the 64-row tile), rows straddling segments, and accumulation into an existing buffer."""
+    from psvo_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + H)
+    dshape = shape[:2] + (Dout,) + shape[3:]
+    X = torch.randn(*shape, generator=g)
+    dOut = torch.randn(*dshape, generator=g)
+    W1 = torch.randn(Din, H, generator=g) / Din ** 0.5
+    b1 = 0.3 * torch.randn(H, generator=g)
+    Wh = torch.randn(H, H, generator=g) / H ** 0.5
+    bh = 0.3 * torch.randn(H, generator=g)
+    W2 = torch.randn(H, Dout, generator=g) / H ** 0.5
+    b2 = 0.3 * torch.randn(Dout, generator=g)
+    ps = [t.double().requires_grad_(True) for t in (W1, b1, Wh, bh, W2, b2)]
+    rows = X.double().movedim(2, -1).reshape(-1, Din)
+    out = torch.relu(torch.relu(rows @ ps[0] + ps[1]) @ ps[2] + ps[3]) @ ps[4] + ps[5]
+    out.backward(dOut.double().movedim(2, -1).reshape(-1, Dout))
+    ref = torch.cat([t.grad.reshape(-1) for t in ps])
+    w = tuple(t.cuda() for t in (W1, b1, W2, b2, Wh, bh))
+    got = ops.mlp_wgrad(X.cuda(), dOut.cuda(), w, Din, H, Dout)
+    torch.cuda.synchronize()
+    assert got.numel() == ref.numel() == ops.mlp_grad_size(Din, H, Dout, 2)
+    off = 0
+    for name, t in zip(("dW1", "db1", "dWh", "dbh", "dW2", "db2"), ps):
+        a, b = got[off:off + t.numel()].double().cpu(), t.grad.reshape(-1)
+        assert torch.allclose(a, b, atol=1e-4 * float(b.abs().max()) + 1e-6, rtol=1e-4), name
+        off += t.numel()
+    acc = torch.ones_like(got)
+    ops.mlp_wgrad(X.cuda(), dOut.cuda(), w, Din, H, Dout, grad=acc)
+    torch.cuda.synchronize()
+    assert torch.allclose(acc, got + 1.0, atol=1e-5 * float(got.abs().max()) + 1e-6, rtol=1e-5)
+    g4 = ops.split_mlp_grad(got, Din, H, Dout, layers=2)
+    assert [tuple(v.shape) for v in g4] == [(Din, H), (H,), (H, Dout), (Dout,), (H, H), (H,)]
 
 
 @pytest.mark.parametrize("R,Din,H,Dout", [(6400, 64, 32, 2), (32, 1, 32, 2), (77, 128, 64, 4), (1000, 3, 16, 1)])

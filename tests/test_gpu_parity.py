@@ -77,6 +77,23 @@ WIDTH_CASES = [
 ]
 
 
+# per-particle MLPs with TWO hidden layers (`*_layers="64,64"`, the example of the reference's flag file,
+# src/runner_flag.py:50-57; src/transformation/MLP.py:24-38,50-54): psvo_desc.layers = 2 in every kernel family -- both filter
+# kernels (four lanes per particle at N <= 128 / H = 32, one lane per particle otherwise), the split-hidden backward
+# simulation, the PSVOwR cluster kernels -- equal, unequal and zero-padded widths, and the MFMA weight gradients
+# (psvo_mlp2_wgrad).  (q1_layers also shapes q1_inv; f_layers only exists without use_bootstrap.)
+DEPTH_CASES = [
+    (("AESMC", 2, 6, 16, 1, 2, 1, 32, True, True), dict(q1_layers="32,32", g_layers="32,32")),
+    (("SVO", 2, 5, 160, 1, 3, 2, 32, False, False), dict(q1_layers="64,64", f_layers="64,64", g_layers="64,64")),
+    (("IWAE", 2, 6, 12, 1, 2, 1, 32, True, False), dict(q1_layers="24,40", g_layers="32,16")),
+    (("PSVO", 2, 6, 16, 8, 2, 1, 32, True, True), dict(q1_layers="32,32", g_layers="32,32")),
+    (("PSVO", 2, 5, 130, 16, 2, 1, 32, False, True), dict(q1_layers="64,64", f_layers="64,64", g_layers="64,64")),
+    (("PSVO", 1, 5, 36, 4, 4, 2, 32, False, False), dict(q1_layers="32,32", f_layers="20,32", g_layers="32,32")),
+    (("PSVOwR", 2, 6, 24, 8, 2, 1, 32, True, True), dict(q1_layers="32,32", g_layers="32,32")),
+    (("PSVOwR", 1, 5, 36, 4, 3, 1, 32, False, True), dict(q1_layers="64,48", f_layers="64,64", g_layers="40,64")),
+]
+
+
 def _setup(obj, B, T, N, M, Dx, Dy, H, bootstrap, two_q, seed=0, **extra):
     from psvo_amd.model import SSM
     from psvo_amd.SMC.SVO import SVO
@@ -407,11 +424,24 @@ def test_bsim_backward_small_transition_scale(built_lib, variant, sigma_f):
     _check_grads(model, P)
 
 
-@pytest.mark.parametrize("case,extra", ENCODER_CASES + EMISSION_CASES + WIDTH_CASES, ids=lambda c: "-".join(map(str, c)) if isinstance(c, tuple) else
-                         ",".join("%s=%s" % kv for kv in c.items()))
+_variant_ids = lambda c: "-".join(map(str, c)) if isinstance(c, tuple) else ",".join("%s=%s" % kv for kv in c.items())
+
+
+@pytest.mark.parametrize("case,extra", ENCODER_CASES + EMISSION_CASES + WIDTH_CASES, ids=_variant_ids)
 def test_encoder_variants(built_lib, case, extra):
     """use_stack_rnn=False (two MultiRNNCells), BSim_use_single_RNN (forward cells only), poisson_emission
     (psvo_desc.emission = 1) and odd / mixed hidden widths: values, indices and every gradient against the oracle."""
+    _variant_against_oracle(case, extra)
+
+
+@pytest.mark.parametrize("case,extra", DEPTH_CASES, ids=_variant_ids)
+def test_two_hidden_layers(built_lib, case, extra):
+    """two hidden layers per particle MLP (psvo_desc.layers = 2; DEPTH_CASES): values, indices and every gradient
+    against the oracle, in all five objectives."""
+    _variant_against_oracle(case, extra)
+
+
+def _variant_against_oracle(case, extra):
     obj = case[0]
     FLAGS, model, smc, obs, noise = _setup(*case, seed=7, **extra)
     z_free, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)

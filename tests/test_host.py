@@ -39,8 +39,10 @@ def test_ssm_inventory_and_sharing():
     m2 = SSM(Hh.make_flags("SVO", use_bootstrap=False))
     assert m2.f_dist is not m2.q1_dist and m2.q2_tran.Din == 64 and m2.q0_tran.Din == 2
     assert tuple(m2.X0_transformer_kernel.shape) == (128, 2)
+    # per-particle MLPs: one hidden layer -> 4 tensors, two -> 6 (hidden_0, mu_layer, hidden_1); three have no kernel
+    assert len(SSM(Hh.make_flags("AESMC", q1_layers="32,32")).q1_tran.hip_params()) == 6
     with pytest.raises(ValueError):
-        SSM(Hh.make_flags("AESMC", q1_layers="32,32")).q1_tran.hip_params()
+        SSM(Hh.make_flags("AESMC", q1_layers="32,32,32")).q1_tran.hip_params()
 
 
 def test_kernel_hidden_width_selection():
@@ -49,7 +51,7 @@ def test_kernel_hidden_width_selection():
     from psvo_amd.SMC.AESMC import AESMC
     F = Hh.make_flags("PSVO", q1_layers="24", f_layers="40", g_layers="16", use_bootstrap=False)
     smc = PSVO(SSM(F), F)
-    assert smc._kernel_width() == (64, True)
+    assert smc._kernel_width() == (64, True, 1)
     W1, b1, W2, b2 = smc._mlp_params(smc.model.g_tran)
     assert tuple(W1.shape) == (F.Dx, 64) and tuple(b1.shape) == (64,) and tuple(W2.shape) == (64, F.Dy)
     assert float(W1[:, 16:].abs().max()) == 0.0 and float(W2[16:].abs().max()) == 0.0
@@ -59,11 +61,50 @@ def test_kernel_hidden_width_selection():
     assert tuple(smc.model.g_tran.kernels[0].grad.shape) == (F.Dx, 16)
     F = Hh.make_flags("AESMC")                                            # defaults: every MLP 32 wide, no padding
     smc = AESMC(SSM(F), F)
-    assert smc._kernel_width() == (32, False)
+    assert smc._kernel_width() == (32, False, 1)
     assert smc._mlp_params(smc.model.q1_tran)[0] is smc.model.q1_tran.kernels[0]
     F = Hh.make_flags("AESMC", g_layers="100")
     with pytest.raises(ValueError):
         AESMC(SSM(F), F)._kernel_width()
+
+
+def test_two_hidden_layers_per_particle_mlp():
+    """`*_layers="a,b"` (reference src/runner_flag.py:50-57, src/transformation/MLP.py:24-38): psvo_desc.layers = 2 at the next
+    two-layer kernel width (32 / 64), both layers zero-padded; mixed depths have no kernel; the flat buffer lays such an MLP
+    out as [W1 | b1 | Wh | bh | W2 | b2], the layout psvo_mlp2_wgrad writes"""
+    from psvo_amd.SMC.PSVO import PSVO
+    from psvo_amd.SMC.AESMC import AESMC
+    from psvo_amd.optim import FlatParams
+    F = Hh.make_flags("PSVO", q1_layers="24,40", g_layers="16,8")
+    m = SSM(F)
+    smc = PSVO(m, F)
+    assert smc._kernel_width() == (64, True, 2)
+    W1, b1, W2, b2, Wh, bh = smc._mlp_params(m.g_tran)
+    assert [tuple(t.shape) for t in (W1, b1, W2, b2, Wh, bh)] == [(F.Dx, 64), (64,), (64, F.Dy), (F.Dy,), (64, 64), (64,)]
+    assert torch.equal(Wh[:16, :8], m.g_tran.kernels[1]) and float(Wh[16:].abs().max()) == 0.0
+    assert float(Wh[:, 8:].abs().max()) == 0.0 and float(W2[8:].abs().max()) == 0.0 and torch.equal(W2[:8], m.g_tran.mu_kernel)
+    x = torch.randn(5, F.Dx)
+    ref = m.g_tran.transform(x)[0]
+    pad = torch.relu(torch.relu(x @ W1 + b1) @ Wh + bh) @ W2 + b2
+    assert torch.allclose(ref, pad, atol=1e-6)
+    first, extra = smc._mlp_args(smc._mlp_params(m.q1_tran), None, smc._mlp_params(m.g_tran))
+    assert len(first) == 12 and first[4:8] == [None] * 4 and len(extra) == 6 and extra[2:4] == [None, None]
+    F = Hh.make_flags("AESMC", q1_layers="16,16", g_layers="16,16")       # (two layers: no 16-wide kernels)
+    smc = AESMC(SSM(F), F)
+    smc.batch_size, smc.time = 2, 5
+    assert smc._kernel_width() == (32, True, 2) and smc._make_desc(1, 32).layers == 2
+    F = Hh.make_flags("AESMC", q1_layers="32,32")                         # g keeps one hidden layer
+    with pytest.raises(ValueError):
+        AESMC(SSM(F), F)._kernel_width()
+    F = Hh.make_flags("AESMC", q1_layers="32,32", g_layers="32,32")
+    m = SSM(F)
+    fp = FlatParams(m)
+    t = m.g_tran
+    n = sum(q.numel() for q in (t.kernels[0], t.biases[0], t.kernels[1], t.biases[1], t.mu_kernel, t.mu_bias))
+    assert t._flat_grad.numel() == n == F.Dx * 32 + 32 + 32 * 32 + 32 + 32 * F.Dy + F.Dy
+    assert t._flat_grad.data_ptr() == t.kernels[0].grad.data_ptr()
+    assert t.mu_bias.grad.data_ptr() == t._flat_grad[n - F.Dy:].data_ptr()
+    assert fp.numel == sum(q.numel() for q in m.parameters())
 
 
 def test_poisson_emission_mirror_matches_oracle_on_cpu():
