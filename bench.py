@@ -37,15 +37,19 @@ WORKLOADS = {
     "C5": ("PSVO", 8, 1000, 512, 4, 1, 16, 32, 32),
     "C*wR": ("PSVOwR", 32, 200, 128, 2, 1, 16, 32, 32),     # C* sizes under the PSVOwR objective (not a headline line)
     "tiny": ("PSVO", 4, 12, 32, 2, 1, 8, 32, 8),            # launcher / multi-rank rehearsals in the tests (not a bench line)
+    # C* sizes with TWO hidden layers per particle MLP (q1 / f / g / q1_inv: `*_layers="H,H"`, the reference's flag-file example
+    # is "64,64", src/runner_flag.py:50-57); optional 10th entry = hidden layers.  Not headline lines.
+    "C*-2x32": ("PSVO", 32, 200, 128, 2, 1, 16, 32, 32, 2),
+    "C*-2x64": ("PSVO", 32, 200, 128, 2, 1, 16, 64, 32, 2),
 }
 FP32_PEAK_TFLOPS = 157.3     # MI355X f32 vector peak == f32-input MFMA dense peak (MI355X_MICROARCH.md)
 EXP_PEAK = 9.8e12            # transcendental quarter rate, exp/s
 
 
-def flop_model(Dx, Dy, N, M, H, E):
+def flop_model(Dx, Dy, N, M, H, E, layers=1):
     """Algorithmic flop per particle-step of each native kernel (forward figures: SURVEY.md section 8(d);
-    backward figures: DESIGN.md section 5).  FMA = 2 flop, exp/log = 1."""
-    mlp = lambda i, o: 2 * H * (i + o)
+    backward figures: DESIGN.md section 5).  FMA = 2 flop, exp/log = 1.  `layers` = 2: an H x H layer more per MLP."""
+    mlp = lambda i, o: 2 * H * (i + o) + (layers - 1) * 2 * H * H
     f_filt = mlp(Dx, Dx) + mlp(Dx, Dy) + mlp(E, Dx) / N + 20 * Dx + 6 * Dy + 10
     f_bsim = 2 * mlp(Dx, Dx) + M * (mlp(Dx, Dx) + mlp(Dx, Dy)) + M * N * (3 * Dx + 4) + M * (14 * Dx + 6 * Dy + 12)
     # reverse passes: MLP forward recompute + input-gradient pass (2x), second pair pass (5 Dx + 6 per pair)
@@ -86,13 +90,14 @@ def build_objective(wl, device, seed=0):
     from psvo_amd.SMC.IWAE import IWAE
     from psvo_amd.SMC.PSVO import PSVO
     from psvo_amd.SMC.SVO import SVO
-    obj, B, T, N, Dx, Dy, M, H, Dh = wl
+    obj, B, T, N, Dx, Dy, M, H, Dh = wl[:9]
     from psvo_amd.SMC.PSVOwR import PSVOwR
     flags = dict(PSVO=False, SVO=False, AESMC=False, IWAE=False, PSVOwR=False)
     flags[obj] = True
     hs = str(H)
+    hp = ",".join([hs] * (wl[9] if len(wl) > 9 else 1))        # per-particle MLPs (hoisted q0 / q2 keep one layer)
     FLAGS = Flags(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, batch_size=B, time=T,
-                  q0_layers=hs, q1_layers=hs, q2_layers=hs, f_layers=hs, g_layers=hs,
+                  q0_layers=hs, q1_layers=hp, q2_layers=hs, f_layers=hp, g_layers=hp,
                   y_smoother_Dhs=str(Dh), X0_smoother_Dhs=str(Dh), **flags)
     torch.manual_seed(seed)
     model = SSM(FLAGS).to(device)
@@ -104,7 +109,7 @@ def cpu_baseline(wl, P, obs_cpu, sample_T, threads, train):
     """Time the CPU oracle (op-for-op restatement of the reference's TF graph, including the
     materialised (M, N, N, B) tile) on the host cores, on the first `sample_T` time steps."""
     from oracle import psvo_oracle as O
-    obj, B, T, N, Dx, Dy, M, H, Dh = wl
+    obj, B, T, N, Dx, Dy, M, H, Dh = wl[:9]
     torch.set_num_threads(threads)
     P = O.params_to(P, torch.float32)
     fl = dict(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, use_bootstrap=True, use_2_q=True,
@@ -149,7 +154,7 @@ def elbo_vs_oracle(wl, P, obs_cpu, sample_T, device, threads):
       * the ELBO of the oracle's own free run is reported beside it (`elbo_oracle_free_run`): it agrees to rounding when no
         index flipped and differs like two independent draws otherwise."""
     from oracle import psvo_oracle as O
-    obj, B, T, N, Dx, Dy, M, H, Dh = wl
+    obj, B, T, N, Dx, Dy, M, H, Dh = wl[:9]
     torch.set_num_threads(threads)
     P64 = O.params_to(P, torch.float64)
     fl = dict(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, use_bootstrap=True, use_2_q=True,
@@ -295,7 +300,8 @@ def main():
     dist = torch.distributed if torch.distributed.is_initialized() else None
 
     wl = WORKLOADS[args.workload]
-    obj, B, T, N, Dx, Dy, M, H, Dh = wl
+    obj, B, T, N, Dx, Dy, M, H, Dh = wl[:9]
+    layers = wl[9] if len(wl) > 9 else 1
     FLAGS, model, smc = build_objective(wl, device, seed=0)
     P_ref = model.export_reference_layout(torch.float32)     # snapshot for the CPU baseline
     smc.generator = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -464,7 +470,7 @@ def main():
                 else:
                     calls.append((name, round(t0c.elapsed_time(open_[name]), 3), round(t0c.elapsed_time(e), 3)))
             print("calls:", calls, file=sys.stderr)
-        flops, x_bsim = flop_model(Dx, Dy, N, M, H, Dy)
+        flops, x_bsim = flop_model(Dx, Dy, N, M, H, Dy, layers)
         cand = {k: v for k, v in kms.items() if k in flops}
         dominant = max(cand, key=lambda k: cand[k][0])
         k_avg = cand[dominant][0] / max(1.0, cand[dominant][1])

@@ -374,6 +374,19 @@ struct MlpLds<DIN, H, DOUT, 2> {
     // The weights are loop-invariant LDS data of a persistent kernel: left visible, hipcc hoists the (DIN + 1) * H reads of the
     // first layer of EVERY MLP out of the time loop (fine for one narrow layer; here it is 3 x 192 registers at H = 64 on top
     // of h and d h: 960 spilled VGPRs in filter_bwd).  An opaque zero offset per call keeps the reads where they are used.
+    // What remains: a result that is only consumed after the NEXT MLP call (dx is the running sum of several calls) has its
+    // tail -- the reads of h and d h -- sunk behind that call's loop, which keeps 2 H registers of every earlier call alive in
+    // it (+230 live values per call at H = 64: AGPR copies at one wave per SIMD, scratch at two).  Pinning the results with an
+    // `asm volatile("" : "+v"(v))` stops the sinking (-DPSVO_PIN_RESULTS: 177 registers whatever the number of calls) but
+    // psvowr_bwd_kernel<3,1,64,4,256> then loses part of its sigma_g sums (one accumulator of 22; every other output
+    // unchanged; not explained -- DESIGN.md section 8), so the product build does not pin.
+#if defined(PSVO_PIN_RESULTS)
+    __device__ __forceinline__ static void pin(float& v) { asm volatile("" : "+v"(v)); }
+    __device__ __forceinline__ static void pin_out(float& v) { asm volatile("" : "+v"(v)); }
+#else
+    __device__ __forceinline__ static void pin(float&) {}
+    __device__ __forceinline__ static void pin_out(float&) {}
+#endif
     __device__ __forceinline__ static const float* opaque(const float* w) {
         int zo = 0;
         asm volatile("" : "+v"(zo));
@@ -405,7 +418,10 @@ struct MlpLds<DIN, H, DOUT, 2> {
             }
         }
 #pragma unroll
-        for (int o = 0; o < DOUT; ++o) out[o] = acc[o].x + acc[o].y;
+        for (int o = 0; o < DOUT; ++o) {
+            out[o] = acc[o].x + acc[o].y;
+            pin_out(out[o]);
+        }
     }
 
     template <bool ROLLED = false>
@@ -447,7 +463,9 @@ struct MlpLds<DIN, H, DOUT, 2> {
             }
             const float d0 = pa.x > 0.f ? da.x : 0.f, d1 = pa.y > 0.f ? da.y : 0.f;
             const float d2 = pb.x > 0.f ? db.x : 0.f, d3 = pb.y > 0.f ? db.y : 0.f;
-            const float* wh = w + kWh + j0;
+            // (a second read of the four columns of Wh: through the pointer pre2_group4 used, hipcc keeps all 4 H values of its
+            //  reads alive -- in AGPRs at one wave per SIMD, in scratch at two -- instead of re-reading them)
+            const float* wh = opaque(w_) + kWh + j0;
 #pragma unroll
             for (int i = 0; i < H; ++i) {
                 const float4 wi = *reinterpret_cast<const float4*>(wh + i * H);
@@ -458,19 +476,25 @@ struct MlpLds<DIN, H, DOUT, 2> {
         f2 dxa[DIN];
 #pragma unroll
         for (int i = 0; i < DIN; ++i) dxa[i] = f2{dx[i], 0.f};
+        // (W1 is read a second time here: through the same pointer hipcc keeps the DIN * H values of hidden1() in registers
+        //  -- or scratch -- across the loop above instead of re-reading them)
+        const float* wt = opaque(w_);
 #pragma unroll
         for (int k = 0; k < H; k += 4) {
             const f2 ga = f2{h[k / 2].x > 0.f ? dh[k] : 0.f, h[k / 2].y > 0.f ? dh[k + 1] : 0.f};
             const f2 gb = f2{h[k / 2 + 1].x > 0.f ? dh[k + 2] : 0.f, h[k / 2 + 1].y > 0.f ? dh[k + 3] : 0.f};
 #pragma unroll
             for (int i = 0; i < DIN; ++i) {
-                const float4 wi = *reinterpret_cast<const float4*>(w + kW1 + i * H + k);
+                const float4 wi = *reinterpret_cast<const float4*>(wt + kW1 + i * H + k);
                 dxa[i] = pk_fma(ga, f2{wi.x, wi.y}, dxa[i]);
                 dxa[i] = pk_fma(gb, f2{wi.z, wi.w}, dxa[i]);
             }
         }
 #pragma unroll
-        for (int i = 0; i < DIN; ++i) dx[i] = dxa[i].x + dxa[i].y;
+        for (int i = 0; i < DIN; ++i) {
+            dx[i] = dxa[i].x + dxa[i].y;
+            pin(dx[i]);
+        }
     }
 
     template <int S>

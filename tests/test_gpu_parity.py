@@ -91,6 +91,13 @@ DEPTH_CASES = [
     (("PSVO", 1, 5, 36, 4, 4, 2, 32, False, False), dict(q1_layers="32,32", f_layers="20,32", g_layers="32,32")),
     (("PSVOwR", 2, 6, 24, 8, 2, 1, 32, True, True), dict(q1_layers="32,32", g_layers="32,32")),
     (("PSVOwR", 1, 5, 36, 4, 3, 1, 32, False, True), dict(q1_layers="64,48", f_layers="64,64", g_layers="40,64")),
+    # the register-hungry corners: Dx = 3 / 4 at H = 64, the 512-thread filter kernels (N > 256), the 512-thread PSVOwR build
+    (("PSVO", 2, 5, 40, 8, 3, 1, 32, True, True), dict(q1_layers="64,64", g_layers="64,64")),
+    (("PSVO", 1, 4, 24, 4, 4, 2, 32, False, True), dict(q1_layers="64,64", f_layers="64,64", g_layers="64,64")),
+    (("AESMC", 2, 5, 300, 1, 4, 1, 32, False, True), dict(q1_layers="64,64", f_layers="64,64", g_layers="64,64")),
+    (("SVO", 2, 6, 100, 1, 3, 1, 32, True, True), dict(q1_layers="32,32", g_layers="32,32")),
+    (("PSVOwR", 2, 5, 130, 16, 2, 1, 32, True, False), dict(q1_layers="32,32", g_layers="32,32")),
+    (("PSVOwR", 1, 5, 36, 4, 3, 1, 32, True, True), dict(q1_layers="64,64", g_layers="64,64")),
 ]
 
 
@@ -546,7 +553,7 @@ def test_padded_width_step_with_flat_gradients_and_hipgraph(built_lib):
     from psvo_amd.optim import FlatParams
     extra = dict(q1_layers="24", g_layers="16")
     FLAGS, model, smc, obs, noise = _setup("PSVO", 2, 8, 16, 8, 2, 1, 32, True, True, seed=4, **extra)
-    assert smc._kernel_width() == (32, True)
+    assert smc._kernel_width() == (32, True, 1)
     nz = Hh.noise_to_hip(noise, "cuda")
     flat = FlatParams(model)
     obs_c = obs.float().cuda()
@@ -569,7 +576,7 @@ def test_padded_width_step_with_flat_gradients_and_hipgraph(built_lib):
         assert (flat.grad - g_e).abs().max() <= 1e-5 * float(g_e.abs().max())
     # the same network at the kernel width: q1 / q1_inv 24 -> 32 and g 16 -> 32 with zero hidden units
     F2, model2, smc2, _, _ = _setup("PSVO", 2, 8, 16, 8, 2, 1, 32, True, True, seed=4)
-    assert smc2._kernel_width() == (32, False)
+    assert smc2._kernel_width() == (32, False, 1)
     sd = model.state_dict()
     with torch.no_grad():
         for k, v in model2.state_dict().items():
