@@ -17,6 +17,12 @@ SOURCES = ["api.hip", "filter_fwd.hip", "bsim_fwd.hip", "lstm.hip", "filter_bwd.
            "bsim_bwd_dx4_l2.hip", "filter_bwd_l2.hip", "filter_fwd_l2.hip"]
 HEADERS = ["common.h", "bsim_bwd_impl.h", "bsim_bwd2_impl.h", os.path.join("..", "..", "include", "psvo_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize"]
+# The two-hidden-layer units hold 2 H values per lane (h1, d h1) on top of the one-layer kernels' state; at H = 64 the greedy
+# register allocator splits live ranges around divergent `if`s and hipcc 7.2 places the copies of such a split ahead of the
+# EXEC restore -- under the `if`'s partial mask -- which silently drops the other lanes' updates (DESIGN.md section 8,
+# tools/exec_restore_check.py).  The basic allocator never splits (a value is stored after every definition and reloaded before
+# every use: lane-exact whatever EXEC is), at the price of more scratch traffic in kernels that are LDS-bound anyway.
+L2_FLAGS = ["-mllvm", "-vgpr-regalloc=basic"]
 
 
 def _stale(target, deps):
@@ -39,7 +45,7 @@ def build_lib(force=False, verbose=True):
         if s.startswith("bsim_bwd_dx"):
             deps.append(os.path.join(CSRC, s.replace("_l2", "")))
         if force or _stale(obj, deps):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + (L2_FLAGS if s.endswith("_l2.hip") else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -517,19 +517,20 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         }
         const bool lead = (m == 0) && h0 && valid;
         float outv[DX];  // per-chain value that is summed over the workgroup: d bmu2 / d minit
+        // The lead lane's sums are selects, not an `if`, and its d mu1 row is stored with the other per-chain rows BEHIND the
+        // MLP pass below: with a divergent region right in front of that pass hipcc 7.2 put the VGPR -> AGPR copies of a
+        // live-range split of acc[] at the region's end, ahead of the EXEC restore, i.e. under the lead-only mask -- every
+        // other lane then lost what it had added to acc[] since the last copy (tools/exec_restore_check.py).
+        float dmu1[DX];
         if (!last) {
-            float dmu1[DX];
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
                 dmu1[d] = dmu[d] * pc[d] * pi1[d];
                 outv[d] = dmu[d] * pc[d] * pi2[d];
-                if (lead) {
-                    a.dmu1[(tb * DX + d) * N + n] = dmu1[d];
-                    acc[AC::kSc + d] += sce[d] + aw * pic[d];   // -sum_m dq_m / c = a / c
-                    acc[AC::kSmm1 + d] += dmu[d] * mu1[d];
-                    acc[AC::kSmb + d] += dmu[d] * bm[d];
-                    acc[AC::kSmm + d] += dmu[d] * mu[d];
-                }
+                acc[AC::kSc + d] += lead ? sce[d] + aw * pic[d] : 0.f;   // -sum_m dq_m / c = a / c
+                acc[AC::kSmm1 + d] += lead ? dmu[d] * mu1[d] : 0.f;
+                acc[AC::kSmb + d] += lead ? dmu[d] * bm[d] : 0.f;
+                acc[AC::kSmm + d] += lead ? dmu[d] * mu[d] : 0.f;
             }
             // MLP_q1inv's input is the same in all G lanes of the chain: spread its hidden units over kQS of them
             {
@@ -545,10 +546,8 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
                 outv[d] = dmu[d];
-                if (lead) {
-                    a.dmu1[(tb * DX + d) * N + n] = 0.f;
-                    acc[AC::kSinit + d] += sce[d] + aw * is_init[d];
-                }
+                dmu1[d] = 0.f;
+                acc[AC::kSinit + d] += lead ? sce[d] + aw * is_init[d] : 0.f;
             }
         }
 #pragma unroll
@@ -558,9 +557,10 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
         // ---- workgroup reductions: d bmu2[t] / d minit, d imean; flush d Fm / d logW partials ---------------------------
         // per-chain rows of d bmu2[t] / d minit / d imean: summed over the chains by the host afterwards (a
         // workgroup sum here would add an LDS round trip to every step of the serial chain)
-        if (m == 0 && h0 && valid) {
+        if (lead) {
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
+                a.dmu1[(tb * DX + d) * N + n] = dmu1[d];
                 a.dbmu2_rows[(tb * DX + d) * N + n] = last ? 0.f : outv[d];
                 if (last) a.dminit_rows[((size_t)b * DX + d) * N + n] = outv[d];
                 if (first) a.dimean_rows[((size_t)b * DX + d) * N + n] = dim[d];

@@ -376,10 +376,9 @@ struct MlpLds<DIN, H, DOUT, 2> {
     // of h and d h: 960 spilled VGPRs in filter_bwd).  An opaque zero offset per call keeps the reads where they are used.
     // What remains: a result that is only consumed after the NEXT MLP call (dx is the running sum of several calls) has its
     // tail -- the reads of h and d h -- sunk behind that call's loop, which keeps 2 H registers of every earlier call alive in
-    // it (+230 live values per call at H = 64: AGPR copies at one wave per SIMD, scratch at two).  Pinning the results with an
-    // `asm volatile("" : "+v"(v))` stops the sinking (-DPSVO_PIN_RESULTS: 177 registers whatever the number of calls) but
-    // psvowr_bwd_kernel<3,1,64,4,256> then loses part of its sigma_g sums (one accumulator of 22; every other output
-    // unchanged; not explained -- DESIGN.md section 8), so the product build does not pin.
+    // it (+230 live values per call at H = 64).  Pinning the results with an `asm volatile("" : "+v"(v))` stops the sinking
+    // (-DPSVO_PIN_RESULTS: 177 registers whatever the number of calls); it is off because these units are built with the
+    // basic register allocator (build.py: L2_FLAGS), where it changes little.
 #if defined(PSVO_PIN_RESULTS)
     __device__ __forceinline__ static void pin(float& v) { asm volatile("" : "+v"(v)); }
     __device__ __forceinline__ static void pin_out(float& v) { asm volatile("" : "+v"(v)); }

@@ -567,34 +567,32 @@ __global__ void __launch_bounds__(MAXT) psvowr_bwd_kernel(const WrBwdArgs a) {
             }
             const bool lead = (m == 0) && valid;
             float outv[DX];
+            // (selects instead of an `if (lead)`, and the d mu1 row stored behind the MLP pass: no divergent region in front
+            //  of that pass -- see the same place in bsim_bwd_impl.h and tools/exec_restore_check.py)
+            float dmu1[DX];
             if (!last) {
-                float dmu1[DX];
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
                     dmu1[d] = dmu[d] * pc[d] * pi1[d];
                     outv[d] = dmu[d] * pc[d] * pi2[d];
-                    if (lead) {
-                        a.dmu1[(tb * DX + d) * N + n] = dmu1[d];
-                        acc[AC::kSc + d] += sce[d] + aw * pic[d];
-                        acc[AC::kSmm1 + d] += dmu[d] * mu1[d];
-                        acc[AC::kSmb + d] += dmu[d] * bm[d];
-                        acc[AC::kSmm + d] += dmu[d] * mu[d];
-                    }
+                    acc[AC::kSc + d] += lead ? sce[d] + aw * pic[d] : 0.f;
+                    acc[AC::kSmm1 + d] += lead ? dmu[d] * mu1[d] : 0.f;
+                    acc[AC::kSmb + d] += lead ? dmu[d] * bm[d] : 0.f;
+                    acc[AC::kSmm + d] += lead ? dmu[d] * mu[d] : 0.f;
                 }
                 MQ::template bwd_input<kRolled>(wqi, xp, dmu1, dxp);
             } else {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
                     outv[d] = dmu[d];
-                    if (lead) {
-                        a.dmu1[(tb * DX + d) * N + n] = 0.f;
-                        acc[AC::kSinit + d] += sce[d] + aw / s_init[d];
-                    }
+                    dmu1[d] = 0.f;
+                    acc[AC::kSinit + d] += lead ? sce[d] + aw / s_init[d] : 0.f;
                 }
             }
             if (lead) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
+                    a.dmu1[(tb * DX + d) * N + n] = dmu1[d];
                     if (!last)     // d loss / d bwXanc_{t+1}[n], polled by the parents' owners at step t+1 (tag t+2)
                         __hip_atomic_store(a.ring + (((size_t)((t + 1) % D) * B + b) * N + n) * kWbWords + d,
                                            ((unsigned long long)(unsigned)(t + 2) << 32) |

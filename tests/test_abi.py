@@ -70,3 +70,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.PsvoHipError):
         _lib.load()
+
+
+@pytest.mark.timeout(900)
+def test_no_register_copies_ahead_of_an_exec_restore(built_lib):
+    """ISA check of every kernel of the library (tools/exec_restore_check.py): in the kernels compiled with hipcc's default
+    (greedy, live-range-splitting) register allocator no VGPR <-> AGPR move or scratch access sits between the skip target of a
+    divergent `if` and the `s_or_b64 exec` that ends it.  hipcc 7.2 placed the copies of a live-range split there under
+    register pressure; they then run under the `if`'s partial EXEC mask and the lanes that skipped the `if` read a stale copy
+    back later -- a two-hidden-layer PSVOwR kernel lost part of one scale gradient that way.  The
+    two-hidden-layer units (namespace psvo::l2) are compiled with the basic allocator instead, which never splits: there a
+    store after each definition and a reload before each use are expected inside divergent regions, and lane-exact.
+    Parity tests sample the instantiated (Dx, Dy, H, M, threads) combinations; this covers all of them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("exec_restore_check", os.path.join(ROOT, "tools", "exec_restore_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    n, rows = chk.scan([built_lib], verbose=False)
+    assert n > 1000, "expected the whole kernel set, scanned %d" % n
+    class_a = [(k, a) for _, k, a, _ in rows if a and "4psvo2l2" not in k]
+    assert not class_a, "register copies ahead of an EXEC restore in: %s" % class_a[:10]
+    from psvo_amd import build
+    assert build.L2_FLAGS == ["-mllvm", "-vgpr-regalloc=basic"]     # (what the exemption of psvo::l2 rests on)
