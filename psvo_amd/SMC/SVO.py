@@ -71,7 +71,7 @@ class SVO:
     _KERNEL_H = (16, 32, 64)
 
     def _particle_mlps(self):
-        """the MLPs evaluated per particle INSIDE the kernels (one hidden layer each; hip_params() raises otherwise)"""
+        """the MLPs evaluated per particle INSIDE the kernels (one or two hidden layers each; hip_params() raises otherwise)"""
         m = self.model
         trans = [m.q1_tran, m.g_tran]
         if not m.use_bootstrap:

@@ -14,7 +14,7 @@ from . import _lib
 
 class FlatParams(object):
     def __init__(self, module):
-        # Layout: the four tensors of every one-hidden-layer MLP first, as [W1 | b1 | W2 | b2] (the layout the native
+        # Layout: the tensors of every MLP with one or two hidden layers first, as [W1 | b1 | (Wh | bh |) W2 | b2] (the layout the native
         # weight-gradient kernels write; nn.Module registration order would put mu_kernel / mu_bias first), then
         # everything else in registration order.  Shared parameters (f == q1 under use_bootstrap) appear once.
         from .transformation.MLP import MLP_transformation
