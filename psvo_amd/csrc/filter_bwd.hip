@@ -758,7 +758,7 @@ static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipS
     const int NT = (a.N + 63) & ~63;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 4 * DX * NT + 16);
     clear_hip_error();
-    constexpr bool kLppOk = (H % 16 == 0) && (H <= 32 && DX <= 3);
+    constexpr bool kLppOk = (H % 16 == 0) && (PSVO_L == 2 || (H <= 32 && DX <= 3));   // (two layers: as in filter_fwd.hip)
     bool lpp = false;
     if constexpr (kLppOk) {
         if (a.N <= 128) {   // latency-bound regime: four lanes per particle

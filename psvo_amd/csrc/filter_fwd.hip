@@ -563,7 +563,9 @@ static int launch_filter(const FilterArgs& a, hipStream_t stream) {
     using MG = MlpLds<DX, H, DY, PSVO_L>;
     // latency-bound regime (N <= 128: at most 512 lanes, 256 VGPRs each): four lanes per particle.  Only the
     // shapes that compile without scratch use it; the rest keep one lane per particle.
-    constexpr bool kLppOk = (H % 16 == 0) && ((H <= 32 && DX <= 3) || H == 16);
+    // (two hidden layers: always -- a lane then walks H / 4 units of the H x H layer instead of all H, and this kernel is a
+    //  latency chain of one workgroup per sequence: C* sizes at "64,64", filter_fwd 6.4 -> 2.0 ms)
+    constexpr bool kLppOk = (H % 16 == 0) && (PSVO_L == 2 || (H <= 32 && DX <= 3) || H == 16);
     if constexpr (kLppOk) {
         if (a.N <= 128) {
             const int NT4 = (4 * a.N + 63) & ~63;

@@ -98,6 +98,9 @@ DEPTH_CASES = [
     (("SVO", 2, 6, 100, 1, 3, 1, 32, True, True), dict(q1_layers="32,32", g_layers="32,32")),
     (("PSVOwR", 2, 5, 130, 16, 2, 1, 32, True, False), dict(q1_layers="32,32", g_layers="32,32")),
     (("PSVOwR", 1, 5, 36, 4, 3, 1, 32, True, True), dict(q1_layers="64,64", g_layers="64,64")),
+    # four lanes per particle at H = 64 and at Dx = 4 (shapes the one-layer build leaves to the lane = particle kernels)
+    (("AESMC", 2, 6, 64, 1, 2, 1, 32, True, True), dict(q1_layers="64,64", g_layers="64,64")),
+    (("SVO", 2, 5, 48, 1, 4, 1, 32, False, True), dict(q1_layers="32,32", f_layers="32,32", g_layers="32,32")),
 ]
 
 
