@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The fp64 oracle is PyTorch on the host: a GPU box shows every core of the machine to torch but grants this job a share of
+    # them (16 for one GPU), and with one thread per visible core the oracle's passes ran 2 - 4 x slower from box to box.
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")
