@@ -52,7 +52,7 @@ def test_hip_path_reproduces_the_oracle_on_the_reference_data(built_lib):
     d = np.load(GOLD)
     obs = torch.tensor(d["Yvalid"][:N_SEQ]).double()
     FLAGS = Hh.make_flags("PSVO", n_particles=16, n_particles_for_BSim_proposal=8, batch_size=N_SEQ, time=200)
-    for seed in SEEDS[:1]:      # (one of the six initialisations of the CPU test above: each costs two T = 200 oracle runs here)
+    for seed in SEEDS[:3]:
         P, noise, z_ref = _oracle_elbo(obs, seed)
         model = SSM(FLAGS).load_reference_layout(O.params_to(P, torch.float32)).cuda()
         smc = PSVO(model, FLAGS)
