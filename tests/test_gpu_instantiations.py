@@ -21,10 +21,10 @@ ONE = [(dx, dy, h, m) for dx, dy, h, m in itertools.product((2, 3, 4), (1, 2), (
 TWO = [(dx, dy, h, m) for dx, dy, h, m in itertools.product((2, 3, 4), (1, 2), (32, 64), (4, 8, 16, 32))]
 
 
-def _run(obj, dx, dy, h, m, layers, k):
+def _run(obj, dx, dy, h, m, layers, k, N=None):
     # alternate the wirings over the sweep so that every family also meets !bootstrap / !two_q; N varies a little
     boot, twoq = (k % 3 != 1), (k % 4 != 3)
-    N = (20, 36, 12)[k % 3]
+    N = (20, 36, 12)[k % 3] if N is None else N
     case = (obj, 1, 4, N, m, dx, dy, h, boot, twoq)
     hp = ",".join([str(h)] * layers)
     extra = dict(q1_layers=hp, g_layers=hp)
@@ -32,7 +32,9 @@ def _run(obj, dx, dy, h, m, layers, k):
         extra["f_layers"] = hp
     FLAGS, model, smc, obs, noise = TP._setup(*case, seed=3 + k % 5, **extra)
     _, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
-    teacher = {"idx_f": ref0["idx_f"], "idx_b": ref0["idx_b"]}
+    teacher = {"idx_f": ref0["idx_f"]} if ref0["idx_f"] is not None else {}
+    if obj in ("PSVO", "PSVOwR"):
+        teacher["idx_b"] = ref0["idx_b"]
     if obj == "PSVOwR":
         teacher["idx_r"] = ref0["idx_r"]
     z_ref, P = TP._oracle_grads(model, FLAGS, obj, obs, noise, teacher)
@@ -70,3 +72,29 @@ def test_every_one_layer_instantiation(built_lib, obj, k, combo):
 @pytest.mark.parametrize("k,combo", list(enumerate(TWO)), ids=lambda v: "-".join(map(str, v)) if isinstance(v, tuple) else None)
 def test_every_two_layer_instantiation(built_lib, obj, k, combo):
     _run(obj, *combo, layers=2, k=k)
+
+
+# The filter kernels alone, in their three shapes -- four lanes per particle (N <= 128 where instantiated), one lane per particle
+# in a 256-thread and in a 512-thread workgroup (N > 256) -- under the three filter-only objectives (AESMC: resampling, IWAE:
+# none, SVO: encoder features), every (Dx, Dy, H) of both depths.
+FILTER = [(dx, dy, h) for dx, dy, h in itertools.product((2, 3, 4), (1, 2), (16, 32, 64))]
+
+
+@pytest.mark.parametrize("N", [40, 160, 300])
+@pytest.mark.parametrize("layers", [1, 2])
+@pytest.mark.parametrize("k,combo", list(enumerate(FILTER)), ids=lambda v: "-".join(map(str, v)) if isinstance(v, tuple) else None)
+def test_every_filter_instantiation(built_lib, k, combo, layers, N):
+    dx, dy, h = combo
+    if layers == 2 and h == 16:
+        pytest.skip("two hidden layers: widths 32 and 64")
+    _run(("AESMC", "IWAE", "SVO")[(k + layers) % 3], dx, dy, h, 4, layers, k + N, N=N)
+
+
+# The 512-thread build of the PSVOwR kernels (more than 256 (chain, m) items per workgroup: N = 130 chains in clusters of 8).
+@pytest.mark.parametrize("layers", [1, 2])
+@pytest.mark.parametrize("k,combo", list(enumerate(FILTER)), ids=lambda v: "-".join(map(str, v)) if isinstance(v, tuple) else None)
+def test_every_wide_psvowr_instantiation(built_lib, k, combo, layers):
+    dx, dy, h = combo
+    if layers == 2 and h == 16:
+        pytest.skip("two hidden layers: widths 32 and 64")
+    _run("PSVOwR", dx, dy, h, 16, layers, k, N=130)
