@@ -140,3 +140,26 @@ def test_data_parallel_gradient_allreduce_gloo():
     res = dict(q.get(timeout=240) for _ in procs)
     [p.join(60) for p in procs]
     assert res == {0: True, 1: True}
+
+
+def test_forced_single_rank_group_runs_the_collectives():
+    """PSVO_FORCE_PG=1: the process group exists for ONE rank too, so the collective call path (broadcast, all-reduce, replica
+    check) is exercised -- how RCCL's initialisation and the in-step all-reduce are driven on a one-GPU box (bench.py)"""
+    import subprocess
+    import sys
+    code = ("import os, torch; os.environ.update(WORLD_SIZE='1', RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', "
+            "PSVO_FORCE_PG='1');\n"
+            "from psvo_amd import dp; import torch.distributed as dist\n"
+            "r, w = dp.init(backend='gloo'); assert (r, w) == (0, 1) and dist.is_initialized() and dp._active()\n"
+            "x = torch.arange(5.); dp.all_reduce_sum_(x); dp.broadcast_(x); assert x.tolist() == [0., 1., 2., 3., 4.]\n"
+            "assert dp.replicas_in_sync(x) and float(dp.all_reduce_mean_scalar(torch.tensor(3.))) == 3.0\n"
+            "dist.destroy_process_group(); print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-2000:]
+    # without the switch a single rank creates no group (and pays for no collective)
+    code2 = ("import os; os.environ.pop('PSVO_FORCE_PG', None); os.environ.update(WORLD_SIZE='1', RANK='0')\n"
+             "from psvo_amd import dp; import torch.distributed as dist\n"
+             "dp.init(backend='gloo'); assert not dist.is_initialized() and not dp._active(); print('ok')\n")
+    p = subprocess.run([sys.executable, "-c", code2], cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-2000:]
