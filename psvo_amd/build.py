@@ -10,11 +10,13 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpsvo_hip.so")
-SOURCES = ["api.hip", "filter_fwd.hip", "bsim_fwd.hip", "lstm.hip", "filter_bwd.hip", "mlp_grad.hip", "bsim_bwd.hip", "bsim_bwd_dx2.hip", "bsim_bwd_dx3.hip", "bsim_bwd_dx4.hip", "bsim_bwd2_dx2.hip", "bsim_bwd2_dx3.hip", "bsim_bwd2_dx4.hip",
-           "lstm_bwd.hip", "adam.hip", "psvowr_fwd.hip", "psvowr_bwd.hip", "rows_mlp.hip", "dense.hip",
-           # two hidden layers per per-particle MLP (psvo_desc.layers == 2): the same sources compiled with PSVO_L = 2
-           "psvowr_bwd_l2.hip", "psvowr_fwd_l2.hip", "bsim_fwd_l2.hip", "bsim_bwd_dx2_l2.hip", "bsim_bwd_dx3_l2.hip",
-           "bsim_bwd_dx4_l2.hip", "filter_bwd_l2.hip", "filter_fwd_l2.hip"]
+# (longest compiles first: with 8 parallel hipcc jobs the build then ends when the work does, not when a late-started
+#  psvowr_bwd unit does; the *_l2 units are the same sources compiled with PSVO_L = 2 -- two hidden layers per particle MLP)
+SOURCES = ["psvowr_bwd_l2.hip", "psvowr_bwd.hip", "bsim_bwd_dx4_l2.hip", "bsim_fwd_l2.hip", "bsim_fwd.hip",
+           "bsim_bwd_dx2_l2.hip", "bsim_bwd_dx3_l2.hip", "psvowr_fwd.hip", "psvowr_fwd_l2.hip", "bsim_bwd_dx4.hip",
+           "bsim_bwd_dx2.hip", "bsim_bwd_dx3.hip", "filter_bwd_l2.hip", "bsim_bwd2_dx2.hip", "filter_bwd.hip",
+           "filter_fwd_l2.hip", "filter_fwd.hip", "bsim_bwd2_dx4.hip", "bsim_bwd2_dx3.hip", "mlp_grad.hip", "lstm_bwd.hip",
+           "lstm.hip", "rows_mlp.hip", "bsim_bwd.hip", "api.hip", "dense.hip", "adam.hip"]
 HEADERS = ["common.h", "bsim_bwd_impl.h", "bsim_bwd2_impl.h", os.path.join("..", "..", "include", "psvo_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize"]
 # The two-hidden-layer units hold 2 H values per lane (h1, d h1) on top of the one-layer kernels' state; at H = 64 the greedy
