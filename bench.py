@@ -253,7 +253,8 @@ def plumbing_only(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node; default: WORLD_SIZE when a launcher has set it, else 1")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="C*", choices=sorted(WORKLOADS))
@@ -273,6 +274,8 @@ def main():
                          "0 = v1 butterflies, 1 = v2 VALU, 2 = v2 with the per-j sums on f32 MFMA, 3 = v2 with the pair exponents on f32 "
                          "MFMA, -1 = library default")
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))      # (no GPU call has been made in this process)
@@ -389,12 +392,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, record):
+    def timed(fn, steps, record, ticks=None):
+        """`steps` calls of fn between two barrier + device syncs, wall clock.  `ticks` (a list) also receives one HIP event
+        per step boundary, recorded on the compute stream without any synchronisation: the spread of the step time."""
         sync()
         rec["on"] = record
+        stream = torch.cuda.current_stream()
         t0 = time.perf_counter()
         for _ in range(steps):
+            if ticks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                ticks.append(e)
             z = fn()
+        if ticks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            ticks.append(e)
         rec["on"] = False
         sync()
         el = time.perf_counter() - t0
@@ -421,7 +435,9 @@ def main():
         z = step()
     # the timed region carries no instrumentation; the per-kernel HIP events (two per native launch) are
     # recorded afterwards on the same step issued eagerly -- they cost ~1 ms per step of host time
-    elapsed, z = timed(step, args.steps, False)
+    ticks = []
+    elapsed, z = timed(step, args.steps, False, ticks)
+    step_ms = sorted(ticks[i].elapsed_time(ticks[i + 1]) for i in range(len(ticks) - 1))
     elbo = float(z.detach())
     eager = train_step if args.mode == "train" else fwd_step
     for _ in range(3):      # (after graph replay the eager path first has to populate its own allocator pool)
@@ -491,7 +507,11 @@ def main():
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3,
+            # spread of the timed steps on rank 0 (HIP events on the compute stream at the step boundaries of the SAME
+            # timed region; `ms_per_step` / `value` stay wall clock over all steps, max over ranks)
+            "step_ms": {"median": step_ms[len(step_ms) // 2], "min": step_ms[0], "max": step_ms[-1], "n": len(step_ms)},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s on Fitzhugh-Nagumo, batch=%d/GPU, T=%d, N=%d, Dx=%d, M=%d, H=%d, Dh=%d"
                                    % (args.workload, obj, B, T, N, Dx, M, H, Dh),
@@ -504,15 +524,16 @@ def main():
                        "bsim_bwd_variant": args.bsim_bwd_variant,
                        "native_ms_per_step": {k: round(v[0], 4) for k, v in sorted(kms.items())},
                        "native_timeline_ms": timeline},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "pipe": "valu", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (HBM, rocprofv3 PMC)",
                          "traffic_source": traffic_src,
                          "kernel": dominant, "kernel_ms_avg": k_avg, "flop_per_particle_step": f_dom,
                          "exp_frac": (units * x_bsim / (k_avg * 1e-3) / EXP_PEAK) if "bsim" in dominant else None,
-                         "note": "bound = the f32 vector ALU (not one of the contract's two labels: the dominant kernel has no "
-                                 "MFMA in its default build and moves 0.5 TB/s): priced against the 157.3 TFLOP/s f32 peak, "
-                                 "which on gfx950 is also the f32-input MFMA peak -- the f32 MFMA variants were measured "
-                                 "beside the VALU kernel and do not co-execute with it (profiles/r02_bsim_bwd_ab.md)"},
+                         "note": "compute-bound, priced against the dense f32 peak of 157.3 TFLOP/s, which on gfx950 is the "
+                                 "f32-input MFMA peak AND the packed f32 vector peak (`bound` keeps the contract's label for "
+                                 "the compute roofline; `pipe` says which pipe executes it: the dominant kernel's default "
+                                 "build issues its flops on the vector ALU -- the f32 MFMA variants were measured beside it "
+                                 "and do not co-execute with the VALU, profiles/r02_bsim_bwd_ab.md; it moves ~0.5 TB/s)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, P_ref, obs.cpu(), min(args.cpu_sample_T, T),

@@ -1,46 +1,60 @@
-"""Result-directory helpers: mirror of the non-plotting part of reference
-src/rslts_saving/rslts_saving.py:14-47 (directory naming, param.json, NumpyEncoder).  The
-matplotlib / seaborn plots are presentation only and out of the MI355X hot-path scope."""
+"""Where a run's results go and how its parameters are recorded.
+
+Same on-disk contract as the reference (src/rslts_saving/rslts_saving.py:14-60, src/rslts_saving/datetools.py:11-21), so that
+its notebooks find what they look for (notebooks/PSVO.ipynb picks the newest directory under rslts/<rslt_dir_name>/ and reads
+history.json and param.json from it):
+
+    <cwd>/rslts/<rslt_dir_name>/D<yymmdd>_<HHMMSS>_<key>_<value>_<key>_<value>.../
+
+with the key/value pairs in the order of the dict the runner passes (np, t, bs, lr, epoch, seed) and `rslt_dir_name` itself
+left out of the suffix; `param.json` maps every flag name to str(value); numpy scalars / arrays inside history.json are
+written as plain JSON numbers / lists.  The plotting half of the reference module (matplotlib, seaborn) is presentation and
+is not built.
+"""
+import datetime
 import json
 import os
-import time
 
 import numpy as np
 
 
+def run_stamp(now=None):
+    """'D<yymmdd>_<HHMMSS>' -- the reference's addDateTime() without its leading underscore"""
+    now = now or datetime.datetime.now()
+    return now.strftime("D%y%m%d_%H%M%S")
+
+
 def addDateTime(s=""):
-    """reference src/rslts_saving/datetools.py: timestamp suffix"""
-    return s + time.strftime("%y%m%d%H%M%S")
+    """reference spelling (datetools.py): the stamp appended to `s` behind an underscore"""
+    return s + "_" + run_stamp()
 
 
 def create_RLT_DIR(Experiment_params):
-    # create the dir to save data
-    cur_date = addDateTime()
-    local_rlt_root = "rslts/" + Experiment_params["rslt_dir_name"] + "/"
-    params_str = ""
-    for param_name, param in Experiment_params.items():
-        if param_name == "rslt_dir_name":
-            continue
-        params_str += "_" + param_name + "_" + str(param)
-    RLT_DIR = os.getcwd().replace("\\", "/") + "/" + local_rlt_root + cur_date + params_str + "/"
-    if not os.path.exists(RLT_DIR):
-        os.makedirs(RLT_DIR)
-    return RLT_DIR
+    """Make (and return, with a trailing slash) the result directory of one run; see the module docstring for the name."""
+    suffix = "".join("_{}_{}".format(key, value) for key, value in Experiment_params.items() if key != "rslt_dir_name")
+    cwd = os.getcwd().replace("\\", "/")
+    path = "/".join([cwd, "rslts", Experiment_params["rslt_dir_name"], run_stamp() + suffix]) + "/"
+    os.makedirs(path, exist_ok=True)
+    return path
 
 
 def save_experiment_param(RLT_DIR, FLAGS):
-    params_dict = {}
-    params_list = sorted([param for param in dir(FLAGS) if not param.startswith("_") and param != "as_dict"])
-    for param in params_list:
-        params_dict[param] = str(getattr(FLAGS, param))
-    with open(RLT_DIR + "param.json", "w") as f:
-        json.dump(params_dict, f, indent=4, cls=NumpyEncoder)
+    """param.json: {flag name: str(value)} for every flag, names sorted; also echoed like the reference does"""
+    flags = FLAGS.as_dict() if hasattr(FLAGS, "as_dict") else {k: v for k, v in vars(FLAGS).items() if not k.startswith("_")}
+    record = {name: str(flags[name]) for name in sorted(flags)}
+    print("Experiment_params:")
+    for name, value in record.items():
+        print("\t{}: {}".format(name, value))
+    with open(os.path.join(RLT_DIR, "param.json"), "w") as fh:
+        json.dump(record, fh, indent=4, cls=NumpyEncoder)
 
 
 class NumpyEncoder(json.JSONEncoder):
+    """json encoder that accepts numpy scalars and arrays (history.json holds lists of np.float64 / R-square arrays)"""
+
     def default(self, obj):
+        if isinstance(obj, np.generic):
+            return obj.item()
         if isinstance(obj, np.ndarray):
             return obj.tolist()
-        if isinstance(obj, (np.floating, np.integer)):
-            return obj.item()
-        return json.JSONEncoder.default(self, obj)
+        return super().default(obj)

@@ -6,7 +6,7 @@ hidden layers: H in {32,64}); round 2 met wrong code in single instantiations un
 copies of a live-range split ahead of the EXEC restore), which no sample would have to hit.  These sweeps run each combination
 of the 256-thread builds through PSVO (both filter kernels' reverse passes, bsim_fwd, bsim_bwd v1 / v2) and through PSVOwR
 (psvowr_fwd / psvowr_bwd); the 512-thread builds are covered by the large-N cases of test_gpu_parity / test_gpu_large.
-Tolerances as in test_gpu_parity: ELBO rel 1e-4, gradients 2e-3 of each tensor's largest entry."""
+Tolerances: ELBO rel 1e-4; gradients 2e-3 of each tensor's largest entry, or 4 x the fp32 oracle's own error on that tensor."""
 import itertools
 
 import pytest
@@ -18,6 +18,7 @@ from tests import test_gpu_parity as TP
 pytestmark = pytest.mark.gpu
 
 ONE = [(dx, dy, h, m) for dx, dy, h, m in itertools.product((2, 3, 4), (1, 2), (16, 32, 64), (4, 8, 16, 32))]
+K32 = 4.0          # accepted multiple of the fp32 oracle's own error (see _run)
 TWO = [(dx, dy, h, m) for dx, dy, h, m in itertools.product((2, 3, 4), (1, 2), (32, 64), (4, 8, 16, 32))]
 
 
@@ -46,20 +47,26 @@ def _run(obj, dx, dy, h, m, layers, k, N=None):
     z.backward()
     torch.cuda.synchronize()
     assert abs(float(z.detach()) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
-    # Tolerance: 2e-3 of a tensor's own largest entry, OR 2e-4 of the largest gradient entry of the whole model.  The second
-    # clause is for q0 in the bootstrap-and-not-2q wiring: d loss / d m0 is a sum over the particles of terms that nearly
-    # cancel (result ~0.04 from terms ~6), so for about one model in ten its fp32 error is 0.4 - 1 % of ITS size while being
-    # < 1e-4 of the terms -- measured alike in the one-layer and two-layer kernels (seed sweeps at Dx = 4, round 2).
+    # Tolerance: 2e-3 of the tensor's own largest entry, or -- where fp32 arithmetic itself cannot do better on this case --
+    # K32 times the error that the ORACLE makes on the same tensor when it is run in fp32 (same parameters, noise and
+    # teacher-forced indices, torch autograd) against its fp64 self.  The second clause is a measured yardstick, per tensor and
+    # per case, not a hand-set one: e.g. in the bootstrap-and-not-2q wiring d loss / d m0 (q0's gradient) is a sum over the
+    # particles of terms that nearly cancel (~0.04 from terms ~6), and the fp32 oracle is then itself 0.3 - 1 % off on every q0
+    # tensor (DESIGN.md section 8 quotes case [35-4-1-32-32-PSVO]).  A tensor that is wrong for any other reason -- a lost
+    # sum, a stale register -- is not excused: the fp32 oracle gets it right.
     pairs = TP._pairs(model, P)
-    top = max(float(ref.grad.abs().max()) for _, _, ref in pairs if ref.grad is not None)
+    _, P32 = TP._oracle_grads(model, FLAGS, obj, obs, noise, teacher, dtype=torch.float32)
+    pairs32 = TP._pairs(model, P32)
     bad = []
-    for name, p, ref in pairs:
+    for (name, p, ref), (_, _, ref32) in zip(pairs, pairs32):
         g = torch.zeros_like(ref) if p.grad is None else p.grad.detach().double().cpu()
         r = torch.zeros_like(ref) if ref.grad is None else ref.grad
+        r32 = torch.zeros_like(ref) if ref32.grad is None else ref32.grad.double()
         err, scale = float((g - r).abs().max()), max(float(r.abs().max()), 1e-6)
-        if err > 2e-3 * scale + 1e-6 and err > 2e-4 * top:
-            bad.append((name, err, scale, top))
-    assert not bad, "gradient mismatch (name, max abs err, own scale, model scale): %s" % bad
+        err32 = float((r32 - r).abs().max())
+        if err > max(2e-3 * scale + 1e-6, K32 * err32):
+            bad.append((name, err, scale, err32))
+    assert not bad, "gradient mismatch (name, max abs err, own scale, fp32 oracle's own err): %s" % bad
 
 
 @pytest.mark.parametrize("obj", ["PSVO", "PSVOwR"])

@@ -210,8 +210,10 @@ def test_bilstm_encoder(built_lib, B, T, Dy, Dhs):
 # ---------------------------------------------------------------------------------------------
 # gradients: hand-written backward kernels vs torch autograd of the fp64 oracle
 # ---------------------------------------------------------------------------------------------
-def _oracle_grads(model, FLAGS, obj, obs, noise, teacher):
-    P = model.export_reference_layout(torch.float64)
+def _oracle_grads(model, FLAGS, obj, obs, noise, teacher, dtype=torch.float64):
+    """ELBO and the autograd gradients of the oracle in `dtype` (fp64: the reference values; fp32: the yardstick of what the
+    arithmetic type itself costs on a given case -- tests/test_gpu_instantiations.py)"""
+    P = model.export_reference_layout(dtype)
     leaves = []
 
     def req(x):
@@ -224,7 +226,8 @@ def _oracle_grads(model, FLAGS, obj, obs, noise, teacher):
             [req(v) for v in x]
     req(P)
     o = O.OBJECTIVES[obj](P, Hh.oracle_flags(FLAGS, obj))
-    z, _ = o.get_log_ZSMC(obs.double(), {**noise, **teacher})
+    nz = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in {**noise, **teacher}.items()}
+    z, _ = o.get_log_ZSMC(obs.to(dtype), nz)
     z.backward()
     return z.detach(), P
 

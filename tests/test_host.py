@@ -2,6 +2,7 @@
 prediction against the oracle, data loading / generation, R-square, and the refusal to run the
 hot path without a GPU (no CPU fallback)."""
 import math
+import os
 import pickle
 
 import numpy as np
@@ -287,3 +288,38 @@ def test_hot_path_refuses_to_run_without_gpu():
     smc = AESMC(SSM(FLAGS), FLAGS)
     with pytest.raises((ValueError, RuntimeError)):
         smc.get_log_ZSMC(torch.zeros(2, 5, 1), None)
+
+
+def test_result_directory_and_param_files_follow_the_reference_naming(tmp_path, monkeypatch):
+    """rslts/<name>/D<yymmdd>_<HHMMSS>_np_.._seed_../ with param.json (str values) -- what the reference's notebooks look for
+    (src/rslts_saving/rslts_saving.py:14-47, notebook output 'RLT_DIR: .../rslts/notebook/D191011_212920_np_16_t_200_bs_1_...')"""
+    import json
+    import re
+    from psvo_amd.rslts_saving.rslts_saving import NumpyEncoder, create_RLT_DIR, save_experiment_param
+    monkeypatch.chdir(tmp_path)
+    params = {"np": 16, "t": 200, "bs": 1, "lr": 0.003, "epoch": 400, "seed": 0, "rslt_dir_name": "notebook"}
+    d = create_RLT_DIR(params)
+    assert d.endswith("/") and os.path.isdir(d)
+    rel = d[len(str(tmp_path).replace("\\", "/")):]
+    assert re.fullmatch(r"/rslts/notebook/D\d{6}_\d{6}_np_16_t_200_bs_1_lr_0\.003_epoch_400_seed_0/", rel), rel
+    FLAGS = Hh.make_flags("PSVO", n_particles=16)
+    save_experiment_param(d, FLAGS)
+    rec = json.load(open(d + "param.json"))
+    assert rec["n_particles"] == "16" and rec["PSVO"] == "True" and list(rec) == sorted(rec)
+    s = json.dumps({"a": np.float32(1.5), "b": np.arange(3), "c": [np.int64(2)]}, cls=NumpyEncoder)
+    assert json.loads(s) == {"a": 1.5, "b": [0, 1, 2], "c": [2]}
+
+
+def test_runner_objective_switch():
+    """exactly one objective flag (src/runner.py:67-81); none raises ValueError, two trip the assert"""
+    from psvo_amd import runner
+    from psvo_amd.SMC.PSVOwR import PSVOwR
+    FLAGS = Hh.make_flags("PSVOwR", n_particles=8)
+    assert isinstance(runner._objective(SSM(FLAGS), FLAGS), PSVOwR)
+    FLAGS = Hh.make_flags("AESMC", n_particles=8)
+    FLAGS.AESMC = False
+    with pytest.raises(ValueError):
+        runner._objective(SSM(FLAGS), FLAGS)
+    FLAGS.AESMC = FLAGS.IWAE = True
+    with pytest.raises(AssertionError):
+        runner._objective(SSM(FLAGS), FLAGS)

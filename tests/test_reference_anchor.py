@@ -5,7 +5,7 @@ M = 8 backward sub-particles, H = 32, Dh = 32, batch 1, T = 200, freshly initial
 TensorFlow's initial weights and random draws cannot be replayed here, so this is a SANITY BAND, not a parity pin (parity
 stays "unpinned": oracle/psvo_oracle.py header): over a handful of fresh initialisations by the
 reference's own initialisers (he_normal kernels, zero biases, softplus-raw sigma 5, LSTM glorot) on the same held-out
-sequences (tests/golden/fhn_obs_slice.npz, sliced from the reference's data file by tests/golden/make_fhn_slice.py), the
+sequences (tests/golden/fhn_notebook.npz, taken from the reference's data file by tests/golden/make_fhn_slice.py), the
 notebook's value must lie inside the range the oracle produces -- fresh-init ELBOs spread over -690 .. -1300, so an objective
 that were off by a missing term, a wrong sign or a wrong normaliser (log N, log M: +-555 / +-416 over 200 steps) would
 leave it -- and on the GPU the HIP path must reproduce each of those oracle values to 1e-3 relative."""
@@ -18,7 +18,7 @@ import torch
 from oracle import psvo_oracle as O
 from tests import helpers as Hh
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fhn_obs_slice.npz")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fhn_notebook.npz")
 FL = dict(Dx=2, Dy=1, n_particles=16, n_particles_for_BSim_proposal=8, use_bootstrap=True, use_2_q=True, objective="PSVO")
 SEEDS = (0, 1, 2, 3, 4, 5)
 N_SEQ = 12
@@ -37,8 +37,8 @@ def test_notebook_initial_elbo_lies_in_the_fresh_init_range_of_the_oracle():
     obs = torch.tensor(d["Yvalid"][:N_SEQ]).double()
     assert obs.shape == (N_SEQ, 200, 1)
     z = [_oracle_elbo(obs, s)[2] for s in SEEDS]
-    nb = float(d["notebook_valid_log_ZSMC"])
-    assert nb == -775.139 and float(d["notebook_train_log_ZSMC"]) == -778.343
+    nb = float(d["nb_valid_log_ZSMC"][0])
+    assert nb == -775.139 and float(d["nb_train_log_ZSMC"][0]) == -778.343 and int(d["nb_iter"][0]) == 1
     assert all(np.isfinite(z))
     assert min(z) < nb < max(z), (nb, z)
     # scale check: a fresh-init step costs 3 .. 7 nats (emission at sigma ~ 5 plus the proposal mismatch), 200 steps
