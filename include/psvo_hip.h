@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PSVO_ABI_VERSION 4
+#define PSVO_ABI_VERSION 5
 
 typedef enum {
     PSVO_OK = 0,
@@ -188,11 +188,15 @@ int psvo_bsim_forward(const psvo_desc* desc,
  *            per-workgroup partials (nblk = psvo_bsim_blocks(desc)) dFm_part (T,B,nblk,Dx,N), dlogW_part (T,B,nblk,N)
  *            and sacc_part (B * nblk * psvo_bsim_acc_size(Dx, Dy) floats) for psvo_bsim_backward_fold;
  *            per-chain rows (to be summed over N): dbmu2_rows (T,B,Dx,N), dminit_rows (B,Dx,N), dimean_rows (B,Dx,N).
- *  The gradient w.r.t. lse is identically zero (the normalised weights' gradients sum to zero).
+ *  The gradient w.r.t. lse is zero analytically (the normalised weights' gradients sum to zero per chain) and of the
+ *  size of its fp32 rounding numerically; it is returned all the same (dlse below), as autodiff of the reference's graph
+ *  carries it: psvo_filter_backward then subtracts the softmax-weighted sum from d logW, which is what keeps that pass
+ *  well-conditioned when the forward particles are far from the data (tests/test_gpu_notebook_curve.py).
  *
  * psvo_bsim_backward_fold (one launch, to be issued right behind): folds the partials in workgroup order into
  *            dFm (T,B,Dx,N), dlogW (T,B,N) = d loss / d (Fm, logW) of the forward filter -> psvo_filter_backward, and the
- *            scale gradients dsig_f, dsig_q1inv, dsig_bq2, dsig_init, disig (Dx), dsig_g (Dy).
+ *            scale gradients dsig_f, dsig_q1inv, dsig_bq2, dsig_init, disig (Dx), dsig_g (Dy);
+ *            dlse (T,B) or NULL = -sum_n dlogW[t,b,n] = d loss / d lse of the forward filter (ABI 5).
  * ------------------------------------------------------------------------------------------- */
 int psvo_bsim_blocks(const psvo_desc* desc);      /* nblk for this problem under the current PSVO_TUNE_BSIM_BWD setting */
 int psvo_bsim_acc_size(int Dx, int Dy);
@@ -213,7 +217,7 @@ int psvo_bsim_backward(const psvo_desc* desc,
 int psvo_bsim_backward_fold(const psvo_desc* desc, const float* dFm_part, const float* dlogW_part, const float* sacc_part,
                             const float* sig_q1inv, const float* sig_bq2, float* dFm, float* dlogW,
                             float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
-                            float* disig, void* stream);
+                            float* disig, float* dlse, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PSVOwR: backward simulation with cross-chain resampling and a per-step ELBO.

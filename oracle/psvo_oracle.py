@@ -36,16 +36,26 @@ LOG2PI = math.log(2.0 * math.pi)
 # --------------------------------------------------------------------------- #
 # L1: transformation / distribution
 # --------------------------------------------------------------------------- #
-def mlp_transform(p, x):
-    """MLP_transformation.transform -- src/transformation/MLP.py:48-68 (output_cov=False).
+def mlp_transform(p, x, with_cov=False):
+    """MLP_transformation.transform -- src/transformation/MLP.py:48-68.
 
-    p = {"layers": [(W, b), ...], "mu": (W, b)}; W is the keras kernel (in, out).
+    p = {"layers": [(W, b), ...], "mu": (W, b)[, "sigma": (W, b)]}; W is the keras kernel (in, out).
+    output_cov and diag_cov (p has a "sigma" head, MLP.py:40-46): the second return value is
+    cov = exp(hidden @ W_sigma + b_sigma) + 1e-6 (MLP.py:58-61), else None.  (The full-covariance head,
+    output_cov without diag_cov, is out of scope: SURVEY.md section 2 row 2.)
     """
     h = x
     for W, b in p["layers"]:
         h = torch.relu(h @ W + b)
     W, b = p["mu"]
-    return h @ W + b
+    mu = h @ W + b
+    if not with_cov:
+        return mu
+    cov = None
+    if p.get("sigma") is not None:
+        Ws, bs = p["sigma"]
+        cov = torch.exp(h @ Ws + bs) + 1e-6
+    return mu, cov
 
 
 def get_sigma(p):
@@ -63,7 +73,10 @@ def diag_log_prob(x, mu, sigma):
 
 
 class OracleMVN:
-    """tf_mvn, diagonal branch -- src/distribution/mvn.py:23-117."""
+    """tf_mvn, diagonal branches -- src/distribution/mvn.py:23-117.
+
+    scale = sigma_con (state-independent, get_sigma) when the transformation has no covariance head, else
+    sigma_con + 0.1 * cov(Input) with cov the MLP's exp head (mvn.py:66-71, output_cov and diag_cov)."""
 
     def __init__(self, p):
         self.p = p
@@ -71,14 +84,24 @@ class OracleMVN:
     def mean(self, Input):                       # mvn.py:104-117
         return mlp_transform(self.p, Input)
 
-    def sigma(self):
-        return get_sigma(self.p)
+    def mean_and_sigma(self, Input):             # get_mvn_from_transformation, mvn.py:51-78
+        mu, cov = mlp_transform(self.p, Input, with_cov=True)
+        s = get_sigma(self.p)
+        if cov is not None:
+            s = s + 0.1 * cov
+        return mu, s
+
+    def sigma(self, Input=None):
+        if self.p.get("sigma") is None:
+            return get_sigma(self.p)
+        return self.mean_and_sigma(Input)[1]
 
     def log_prob(self, Input, output):           # mvn.py:99-102
-        return diag_log_prob(output, self.mean(Input), self.sigma())
+        mu, s = self.mean_and_sigma(Input)
+        return diag_log_prob(output, mu, s)
 
     def sample_and_log_prob(self, Input, eps):   # mvn.py:92-97; eps has the full sample shape
-        mu, s = self.mean(Input), self.sigma()
+        mu, s = self.mean_and_sigma(Input)
         x = mu + s * eps
         return x, diag_log_prob(x, mu, s)
 
@@ -272,8 +295,8 @@ class OracleSVO:
 
     # -- SVO.py:182-232, diagonal branch
     def sample_from_2_dist(self, dist1, dist2, d1_input, d2_input, eps):
-        m1, s1 = dist1.mean(d1_input), dist1.sigma()
-        m2, s2 = dist2.mean(d2_input), dist2.sigma()
+        m1, s1 = dist1.mean_and_sigma(d1_input)          # (.mean(), .stddev() of the two MultivariateNormalDiag)
+        m2, s2 = dist2.mean_and_sigma(d2_input)
         s1_inv, s2_inv = 1 / s1, 1 / s2
         combined_cov = 1 / (s1_inv + s2_inv)
         combined_mean = combined_cov * (s1_inv * m1 + s2_inv * m2)
@@ -500,7 +523,7 @@ def he_normal(gen, fan_in, fan_out, dtype):
     return (z * std).to(dtype)
 
 
-def make_mlp(gen, Din, Dhs, Dout, sigma_init, sigma_min, dtype, bias_scale=0.0):
+def make_mlp(gen, Din, Dhs, Dout, sigma_init, sigma_min, dtype, bias_scale=0.0, cov_head=False):
     layers, d = [], Din
     for Dh in Dhs:
         b = torch.zeros(Dh, dtype=dtype)
@@ -511,8 +534,11 @@ def make_mlp(gen, Din, Dhs, Dout, sigma_init, sigma_min, dtype, bias_scale=0.0):
     b = torch.zeros(Dout, dtype=dtype)
     if bias_scale:
         b = (torch.randn(Dout, generator=gen, dtype=torch.float64) * bias_scale).to(dtype)
-    return {"layers": layers, "mu": (he_normal(gen, d, Dout, dtype), b),
-            "sigma_raw": torch.full((Dout,), float(sigma_init), dtype=dtype), "sigma_min": float(sigma_min)}
+    out = {"layers": layers, "mu": (he_normal(gen, d, Dout, dtype), b),
+           "sigma_raw": torch.full((Dout,), float(sigma_init), dtype=dtype), "sigma_min": float(sigma_min)}
+    if cov_head:      # sigma_layer: he_normal kernel, bias Constant(1.0) (MLP.py:40-46), diag_cov: Dout outputs
+        out["sigma"] = (he_normal(gen, d, Dout, dtype), torch.ones(Dout, dtype=dtype))
+    return out
 
 
 def make_lstm(gen, Din, Dh, dtype):
@@ -539,7 +565,10 @@ def make_params(flags, seed=0, dtype=torch.float64, bias_scale=0.0):
     q0_in = E0 if both else Dx
     si, sm = flags.get("sigma_init", 5.0), flags.get("sigma_min", 1.0)
     H = flags.get("layers", [32])
-    mk = lambda i, o: make_mlp(gen, i, H, o, si, sm, dtype, bias_scale)
+    cov_head = bool(flags.get("output_cov", False))
+    if cov_head and not flags.get("diag_cov", False):
+        raise NotImplementedError("full-covariance head (output_cov without diag_cov): out of scope, SURVEY.md section 2")
+    mk = lambda i, o: make_mlp(gen, i, H, o, si, sm, dtype, bias_scale, cov_head=cov_head)
     P = {"q0": mk(q0_in, Dx), "q1": mk(Dx, Dx)}
     if flags["use_2_q"]:
         P["q2"] = mk(E, Dx)

@@ -55,7 +55,7 @@ SIGNATURES = {
     "psvo_get_tuning": (ctypes.c_int, [ctypes.c_int]),
     "psvo_bsim_acc_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "psvo_bsim_backward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 28),
-    "psvo_bsim_backward_fold": (ctypes.c_int, [_DESC] + [_P] * 14),
+    "psvo_bsim_backward_fold": (ctypes.c_int, [_DESC] + [_P] * 15),
     "psvo_bsimwr_blocks": (ctypes.c_int, [ctypes.c_int] * 3),
     "psvo_bsimwr_ws_floats": (ctypes.c_longlong, [ctypes.c_int] * 3),
     "psvo_bsimwr_forward": (ctypes.c_int, [_DESC] + [_P] * 3 + [_MLP, _MLP, _MLP] + [_P] * 25 + [_P]),

@@ -35,6 +35,9 @@ PRELAUNCH = os.environ.get("PSVO_PRELAUNCH", "1") != "0"
 # i.e. BEHIND the small launches of the encoder's reverse chain, which otherwise run beside them on a full card
 DEFER_BSIM_WGRAD = os.environ.get("PSVO_DEFER_BSIM_WGRAD", "1") != "0"
 _PENDING_WORK = []
+# A/B switch (off: measured, section 1 of DESIGN.md): the filter's MLP_g weight gradient on the second side stream
+SPLIT_FILTER_WGRAD = os.environ.get("PSVO_FILTER_WGRAD_SPLIT", "0") == "1"
+SPLIT_CROSS_WAIT = False      # tools/capture_probe.py only: reproduce the cross-wait crash of hip::Stream::EndCapture
 
 
 def join_deferred():
@@ -229,15 +232,29 @@ class FilterFunction(torch.autograd.Function):
                 fn()
             if ov.bsim_wgrad_done is not None:       # (recorded on the second side stream when used)
                 side.wait_event(ov.bsim_wgrad_done)
+            # PSVO_FILTER_WGRAD_SPLIT=1: MLP_g's weight gradient on the second side stream beside MLP_q1's (they write
+            # different slices of the flat gradient buffer; that stream already carries the backward simulation's weight
+            # gradients, i.e. it is ordered after their write of g's slice and is joined below with `side`)
+            split = (SPLIT_FILTER_WGRAD and ctx.gbufs is not None and DEFER_JOIN and ov.side2 is not None
+                     and ov.bsim_wgrad_done is not None)
+            after = kernel_done
+            if split and not SPLIT_CROSS_WAIT:
+                # `side` already waits for an event of `side2` (bsim_wgrad_done); a wait of side2 on an event of `side` would
+                # close a cycle in the runtime's fork relation and hip::Stream::EndCapture (ROCm 7.2) recurses over that
+                # relation without a visited set -- stack overflow, SIGSEGV (gpurun_out/r3/gdb_gsplit.log).  The kernel's
+                # completion is therefore relayed through the main stream.
+                main.wait_event(kernel_done)
+                after = torch.cuda.Event()
+                after.record(main)
             with ops.launch_on(side):
-                r.pop("_wgrad")()
+                r.pop("_wgrad")(ov.side2 if split else None, after)
             if ctx.gbufs is not None and DEFER_JOIN:
                 # the weight gradients accumulate straight into the flat gradient buffer: nothing downstream on the main
                 # stream reads them, so the main stream (hoisted q2 / q0 backward, scale gradients) continues as soon as
                 # the reverse KERNEL is done and the weight-gradient launches overlap it; the caller joins the streams once,
                 # after backward() and before it touches the gradients (autograd.join_deferred(): trainer, bench).
-                # (Issuing MLP_g's weight gradient on the second side stream, beside MLP_q1's, takes the process down
-                #  inside hipStreamEndCapture on ROCm 7.2 -- tried twice this round, ~20 us at stake -- and is not done.)
+                # (The abort recorded in round 2 -- "MLP_g's weight gradient on the second side stream takes the process down
+                #  inside hipStreamEndCapture" -- is explained: see `split` above and DESIGN.md section 1.)
                 main.wait_event(kernel_done)
                 _PENDING_JOIN.extend(st for st in (side, ov.side2) if st is not None)
             else:
@@ -315,9 +332,9 @@ class BsimFunction(torch.autograd.Function):
                 ov.bsim_grads_ready = torch.cuda.Event()
                 ov.bsim_grads_ready.record()
                 if PRELAUNCH and ctx.filter_node is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]):
-                    # (lse receives no gradient from this node: d lse is None unless the loss reads lse itself, in which
-                    #  case backward() sees other upstream gradients than these and launches again)
-                    ov.pre = FilterFunction.launch_reverse_kernel(ctx.filter_node, None, out["dFm"], out["dlogW"])
+                    # (d lse = -sum_n d logW: zero analytically, rounding-sized numerically, passed on as autodiff of the
+                    #  reference's graph would -- ops.bsim_backward / bsim_bwd_fold_finalize)
+                    ov.pre = FilterFunction.launch_reverse_kernel(ctx.filter_node, out["dlse"], out["dFm"], out["dlogW"])
         ws = None if (ov is None or ctx.gbufs is None) else ov.side2
         defer = (DEFER_BSIM_WGRAD and DEFER_JOIN and PRELAUNCH and ws is not None and ctx.filter_node is not None
                  and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]))
@@ -343,7 +360,7 @@ class BsimFunction(torch.autograd.Function):
                                     2 if desc.layers == 2 else 1, ctx.gbufs or (None, None, None))
         dFm, dlogW = r["dFm"], r["dlogW"]
         ops.sum_chain_rows(r, desc.T, desc.B, Dx)       # (one reduction for d bmu2 / d minit / d imean)
-        return (None, None, None, None, None, dFm, dlogW, None) + gfirst + (
+        return (None, None, None, None, None, dFm, dlogW, r["dlse"] if ctx.needs_input_grad[7] else None) + gfirst + (
             r["dsig_f"], r["dsig_g"], r["dsig_q1inv"], r["dsig_bq2"], r["dbmu2"],
             r["dminit"], r["dsig_init"], r["dimean"], r["disig"]) + gextra
 

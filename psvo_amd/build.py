@@ -17,14 +17,17 @@ SOURCES = ["psvowr_bwd_l2.hip", "psvowr_bwd.hip", "bsim_bwd_dx4_l2.hip", "bsim_f
            "bsim_bwd_dx2.hip", "bsim_bwd_dx3.hip", "filter_bwd_l2.hip", "bsim_bwd2_dx2.hip", "filter_bwd.hip",
            "filter_fwd_l2.hip", "filter_fwd.hip", "bsim_bwd2_dx4.hip", "bsim_bwd2_dx3.hip", "mlp_grad.hip", "lstm_bwd.hip",
            "lstm.hip", "rows_mlp.hip", "bsim_bwd.hip", "api.hip", "dense.hip", "adam.hip"]
-HEADERS = ["common.h", "bsim_bwd_impl.h", "bsim_bwd2_impl.h", os.path.join("..", "..", "include", "psvo_hip.h")]
+HEADERS = ["common.h", "mlp2_valu.h", os.path.join("..", "..", "include", "psvo_hip.h")]      # every unit includes these
+# headers only some units include (a change of bsim_bwd2_impl.h rebuilds 4 units, not 27)
+UNIT_HEADERS = {"bsim_bwd_impl.h": ("bsim_bwd_dx", "bsim_bwd2_dx", "bsim_bwd.hip"),
+                "bsim_bwd2_impl.h": ("bsim_bwd2_dx", "bsim_bwd.hip")}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize"]
-# The two-hidden-layer units hold 2 H values per lane (h1, d h1) on top of the one-layer kernels' state; at H = 64 the greedy
-# register allocator splits live ranges around divergent `if`s and hipcc 7.2 places the copies of such a split ahead of the
-# EXEC restore -- under the `if`'s partial mask -- which silently drops the other lanes' updates (DESIGN.md section 8,
-# tools/exec_restore_check.py).  The basic allocator never splits (a value is stored after every definition and reloaded before
-# every use: lane-exact whatever EXEC is), at the price of more scratch traffic in kernels that are LDS-bound anyway.
-L2_FLAGS = ["-mllvm", "-vgpr-regalloc=basic"]
+# Round 2 built the two-hidden-layer units with `-mllvm -vgpr-regalloc=basic`: their per-lane H x H layer held 2 H values per
+# lane and under that pressure the default (greedy) allocator split live ranges around divergent regions, with hipcc 7.2 placing
+# the copies of such a split ahead of the EXEC restore (tools/exec_restore_check.py).  Since round 3 the
+# H x H layer runs on the matrix pipe (common.h: MlpLds<.., 2>) and needs ~80 registers; all units are built with the default
+# allocator again and ALL kernels are held to the ISA check (tests/test_abi.py).  PSVO_L2_BASIC=1 restores the old flags.
+L2_FLAGS = ["-mllvm", "-vgpr-regalloc=basic"] if os.environ.get("PSVO_L2_BASIC", "0") == "1" else []
 
 
 def _stale(target, deps):
@@ -46,6 +49,7 @@ def build_lib(force=False, verbose=True):
             deps.append(os.path.join(CSRC, s.replace("_l2.hip", ".hip")))       # (#include "X.hip")
         if s.startswith("bsim_bwd_dx"):
             deps.append(os.path.join(CSRC, s.replace("_l2", "")))
+        deps += [os.path.join(CSRC, h) for h, users in UNIT_HEADERS.items() if s.startswith(users)]
         if force or _stale(obj, deps):
             jobs.append([hipcc] + FLAGS + (L2_FLAGS if s.endswith("_l2.hip") else []) + ["-c", src, "-o", obj])
 

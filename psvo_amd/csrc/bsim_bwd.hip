@@ -57,6 +57,7 @@ extern "C" int psvo_get_tuning(int key) {
 
 extern "C" int psvo_bsim_blocks(const psvo_desc* desc) {
     if (!desc) return PSVO_ERR_INVALID;
+    if (!psvo::desc_layers_ok(desc)) return PSVO_ERR_UNSUPPORTED;
     int HS, NTB, cpb, nblk;
     if (bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy, desc->layers) != 0)
         psvo::bsim2_geometry(desc->N, desc->M, cpb, nblk);
@@ -81,7 +82,7 @@ extern "C" int psvo_bsim_backward(
         !dminit_rows || !dimean_rows || !sacc_part)
         return PSVO_ERR_INVALID;
     if (desc->B <= 0 || desc->T < 2 || desc->N <= 0 || desc->M <= 0) return PSVO_ERR_INVALID;
-    if (desc->N > 1024 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
+    if (desc->N > 1024 || desc->B > 65535 || !desc_layers_ok(desc)) return PSVO_ERR_UNSUPPORTED;
 
     BsimBwdArgs a;
     a.B = desc->B; a.T = desc->T; a.N = desc->N; a.emission = desc->emission;
@@ -138,7 +139,7 @@ static int fold_dispatch_dy(const BsimBwdArgs& a, const BsimBwdOut& o, int Dy, i
 extern "C" int psvo_bsim_backward_fold(const psvo_desc* desc, const float* dFm_part, const float* dlogW_part,
                                        const float* sacc_part, const float* sig_q1inv, const float* sig_bq2, float* dFm,
                                        float* dlogW, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2,
-                                       float* dsig_init, float* disig, void* stream) {
+                                       float* dsig_init, float* disig, float* dlse, void* stream) {
     using namespace psvo;
     if (!desc || !dFm_part || !dlogW_part || !sacc_part || !sig_q1inv || !sig_bq2 || !dFm || !dlogW || !dsig_f ||
         !dsig_g || !dsig_q1inv || !dsig_bq2 || !dsig_init || !disig)
@@ -149,7 +150,7 @@ extern "C" int psvo_bsim_backward_fold(const psvo_desc* desc, const float* dFm_p
     a.dFm_part = const_cast<float*>(dFm_part); a.dlogW_part = const_cast<float*>(dlogW_part);
     a.sacc_part = const_cast<float*>(sacc_part);
     a.sig_q1inv = sig_q1inv; a.sig_bq2 = sig_bq2;
-    BsimBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig, dFm, dlogW};
+    BsimBwdOut o{dsig_f, dsig_g, dsig_q1inv, dsig_bq2, dsig_init, disig, dFm, dlogW, dlse};
     const int nblk = psvo_bsim_blocks(desc);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     using MQ = MlpLds<DX, H, DX, 1>;
     using MG = MlpLds<DX, H, DY, 1>;
     using AC = BAcc<DX, DY>;
-    constexpr int PS = (JM == 3) ? 20 : BTileSlot<DX>::kFloats;
+    constexpr int PS = (JM == 3) ? 20 : (DX == 4 && JM == 0) ? 5 : BTileSlot<DX>::kFloats;   // floats per tile entry
     constexpr int FO = (JM == 3) ? 16 : 0;    // F'_0, F'_1 inside a slot (JM >= 2)
     constexpr int NA = DX + 1;            // per-j accumulators: d F' (DX) and d W^
     constexpr int PART = 2;               // lanes per (chain, m) in the per-(chain, m) phases
@@ -156,7 +156,16 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     constexpr int UVS = (2 * DX + 3) & ~3;   // floats per (chain, m) of the U / V hand-back, padded to float4s
     // forward-particle tiles (of 16) per chunk whose per-j sums live in registers (the MFMA accumulators take four
     // registers per tile where the VALU form takes NA: half the tiles per chunk keep it inside the 256-VGPR budget)
-    constexpr int JC = (JM || DX >= 3) ? 4 : 8;   // (Dx >= 3: the per-(chain, m) sums of both rounds take 16 Dx registers)
+    constexpr int JC = (JM || DX >= 3) ? 4 : 8;   // (Dx >= 3: register budget)
+    // RO ("rounds outer", Dx >= 3, round 3): the two rounds of items of a lane group are walked one after the other over the
+    // WHOLE tile instead of inside every chunk, so only one round's U / V sums (8 Dx registers, not 16 Dx) are live; the
+    // per-j sums of a chunk are then flushed once per (round, chunk) and round 1 ADDS to round 0's value in the wave's LDS
+    // copy (same lane, same address: ordered).  With the other register savings below this is what lets the Dx = 4 kernel run
+    // two waves per SIMD without scratch.
+    constexpr bool RO = (DX >= 3) && (JM == 0);
+    // Dx = 4, VALU form: the tile is kept as F'[NP] (float4) + W'[NP] (float) -- 20 B per forward particle instead of the
+    // 32 B of the padded slot -- so that two workgroups fit a CU's LDS at N = 512 (C5)
+    constexpr bool kSplitTile = (DX == 4) && (JM == 0);
     static_assert(CM == 32 && (M % 4) == 0, "two lanes per (chain, m): M in {4, 8, 16, 32}");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -272,9 +281,22 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
             v.z = DX > 2 ? F[DX > 2 ? 2 : 0] : 0.f;
             v.w = W;
             *reinterpret_cast<float4*>(buf + j * PS) = v;
+        } else if constexpr (kSplitTile) {
+            *reinterpret_cast<float4*>(buf + 4 * j) = make_float4(F[0], F[1], F[2], F[3]);
+            buf[4 * NP + j] = W;
         } else {
             *reinterpret_cast<float4*>(buf + j * PS) = make_float4(F[0], F[1], F[2], F[3]);
             *reinterpret_cast<float4*>(buf + j * PS + 4) = make_float4(W, 0.f, 0.f, 0.f);
+        }
+    };
+    // entry j of a staged tile
+    auto tile_entry = [&](const float* buf, int j, float (&F)[DX], float& W) {
+        if constexpr (kSplitTile) {
+            const float4 e = *reinterpret_cast<const float4*>(buf + 4 * j);
+            F[0] = e.x; F[DX > 1 ? 1 : 0] = e.y; F[DX > 2 ? 2 : 0] = e.z; F[DX > 3 ? 3 : 0] = e.w;
+            W = buf[4 * NP + j];
+        } else {
+            read_slot<DX>(buf + j * PS, F, W);
         }
     };
     auto get_slot = [&](int tt, int j, float (&raw)[DX + 1]) {
@@ -304,20 +326,37 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     }
     __syncthreads();
 
-    // scalar accumulators of the scale gradients: registers for Dx <= 2; for Dx >= 3 (7 Dx + Dy of them, live across the
-    // pair phase, where the kernel is at its 256-VGPR budget) one wave-private LDS word per lane, updated with ds_add_f32
+    // scalar accumulators of the scale gradients: registers for Dx <= 2.  For Dx >= 3 (7 Dx + Dy of them, live across the pair
+    // phase, where the kernel is at its 256-VGPR budget) wave-private LDS words updated with ds_add_f32 -- one per
+    // (chain, m) for the sums every sub-particle contributes to (sigma_f, the t = 0 prior scale, sigma_g: 32 slots each) and
+    // one per chain for the sums only the chain's lead lane holds (the four product-of-Gaussians sums, sigma_init).
+    // (Round 2 kept one word per LANE for all of them: 29 KB at Dx = 4, a third of what a workgroup may use if two are to
+    //  share a CU at N = 512.)
     constexpr bool kAccLds = (DX >= 3);
+    constexpr int kRowsA = 2 * DX + DY, kRowsB = 5 * DX, kSlotsB = 8;      // (at most 8 chains per wave: M = 4)
     float acc[kAccLds ? 1 : AC::kN];
-    float* const accl = red + 16 + wave * AC::kN * 64;       // [nwv][kN][64] (kAccLds only)
+    float* const accA = red + 16 + wave * (kRowsA * 32 + kRowsB * kSlotsB);     // [nwv][kRowsA][32] + [kRowsB][8]
+    float* const accB = accA + kRowsA * 32;
+    auto acc_is_lead = [](int k) { return k < 4 * DX || (k >= 5 * DX && k < 6 * DX); };
+    auto acc_row = [](int k) {      // row inside accA / accB
+        return k < 4 * DX ? k : k < 5 * DX ? k - 4 * DX : k < 6 * DX ? 4 * DX + (k - 5 * DX)
+               : k < 7 * DX ? DX + (k - 6 * DX) : 2 * DX + (k - 7 * DX);
+    };
+    const int s32 = cl * M + m;          // (chain, m) slot of the wave
     if constexpr (kAccLds) {
-        for (int i = 0; i < AC::kN; ++i) accl[i * 64 + lane] = 0.f;
+        for (int i = lane; i < kRowsA * 32 + kRowsB * kSlotsB; i += 64) accA[i] = 0.f;
     } else {
 #pragma unroll
         for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
     }
+    // (every caller is a part-0 lane -- one per (chain, m) -- and the per-chain sums come from the chain's lead lane alone)
     auto acc_add = [&](int k, float v) {
-        if constexpr (kAccLds) atomicAdd(&accl[k * 64 + lane], v);
-        else acc[k] += v;
+        if constexpr (kAccLds) {
+            if (acc_is_lead(k)) atomicAdd(&accB[acc_row(k) * kSlotsB + cl], v);
+            else atomicAdd(&accA[acc_row(k) * 32 + s32], v);
+        } else {
+            acc[k] += v;
+        }
     };
     float dX[DX];  // d loss / d bwX_t of this chain (all lanes of the chain hold the same value)
 #pragma unroll
@@ -410,6 +449,98 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // ---- pair phase: lane = (j16, g); item of round r: it = 4 r + g = (chain, quad) ---------------------------
+            if constexpr (RO) {
+#pragma unroll 1
+                for (int r = 0; r < 2; ++r) {
+                    const int it4 = 4 * (4 * r + g);          // first (chain, m) slot of the item
+                    f2 xa[DX], xb[DX], Ua[DX], Ub[DX], Va[DX], Vb[DX];
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) {
+                        const float4 v = *reinterpret_cast<const float4*>(xw + d * CM + it4);
+                        xa[d] = f2{v.x, v.y};
+                        xb[d] = f2{v.z, v.w};
+                        Ua[d] = Ub[d] = Va[d] = Vb[d] = f2{0.f, 0.f};
+                    }
+                    const float4 lq = *reinterpret_cast<const float4*>(xw + DX * CM + it4);
+                    const float4 dl = *reinterpret_cast<const float4*>(xw + (DX + 1) * CM + it4);
+                    const f2 lqa = f2{lq.x, lq.y}, lqb = f2{lq.z, lq.w};
+                    const f2 dla = f2{dl.x, dl.y}, dlb = f2{dl.z, dl.w};
+#pragma unroll 1
+                    for (int c = 0; c < nch; ++c) {
+                        float A2[JC][NA];
+#pragma unroll
+                        for (int jt = 0; jt < JC; ++jt) {
+                            float F[DX], W;
+                            tile_entry(cur, (c * JC + jt) * 16 + j16, F, W);
+                            f2 ua[DX], ub[DX], la = f2{W, W}, lb = la;
+#pragma unroll
+                            for (int d = 0; d < DX; ++d) {
+                                const f2 Fd = f2{F[d], F[d]};
+                                ua[d] = xa[d] - Fd;
+                                ub[d] = xb[d] - Fd;
+                                la = pk_fma(-ua[d], ua[d], la);
+                                lb = pk_fma(-ub[d], ub[d], lb);
+                            }
+                            la -= lqa;
+                            lb -= lqb;
+                            const f2 pa = f2{exp2_fast(la.x), exp2_fast(la.y)}, pb = f2{exp2_fast(lb.x), exp2_fast(lb.y)};
+                            const f2 ca = dla * pa, cb = dlb * pb;
+#pragma unroll
+                            for (int d = 0; d < DX; ++d) {
+                                const f2 pua = pa * ua[d], pub = pb * ub[d];
+                                Ua[d] += pua;
+                                Ub[d] += pub;
+                                Va[d] = pk_fma(pua, ua[d], Va[d]);
+                                Vb[d] = pk_fma(pub, ub[d], Vb[d]);
+                            }
+                            const f2 cs = ca + cb;
+                            A2[jt][DX] = cs.x + cs.y;
+#pragma unroll
+                            for (int d = 0; d < DX; ++d) {
+                                const f2 ad = pk_fma(cb, ub[d], ca * ua[d]);
+                                A2[jt][d] = ad.x + ad.y;
+                            }
+                        }
+                        // flush: reduce over the four lane groups, one owner lane per (j, e); round 1 adds to round 0's value
+#pragma unroll
+                        for (int jt = 0; jt < JC / 2; ++jt)
+#pragma unroll
+                            for (int e = 0; e < NA; ++e) A2[jt][e] = swap_add32(A2[jt][e], A2[jt + JC / 2][e]);
+#pragma unroll
+                        for (int jt = 0; jt < JC / 4; ++jt)
+#pragma unroll
+                            for (int e = 0; e < NA; ++e) A2[jt][e] = swap_add16(A2[jt][e], A2[jt + JC / 4][e]);
+                        const int jt0 = (JC / 2) * (g >> 1) + (JC / 4) * (g & 1);
+#pragma unroll
+                        for (int jt = 0; jt < JC / 4; ++jt) {
+#pragma unroll
+                            for (int e = 0; e < NA; ++e) {
+                                float* dst = ja + e * NP + (c * JC + jt0 + jt) * 16 + j16;
+                                *dst = (r == 0) ? A2[jt][e] : *dst + A2[jt][e];
+                            }
+                        }
+                    }
+                    // U, V of the round's item: sum over the 16 forward particles of the row, hand back per (chain, m)
+                    float vv[4 * 2 * DX], o[UVS];
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) {
+                        vv[0 * 2 * DX + d] = Ua[d].x; vv[1 * 2 * DX + d] = Ua[d].y;
+                        vv[2 * 2 * DX + d] = Ub[d].x; vv[3 * 2 * DX + d] = Ub[d].y;
+                        vv[0 * 2 * DX + DX + d] = Va[d].x; vv[1 * 2 * DX + DX + d] = Va[d].y;
+                        vv[2 * 2 * DX + DX + d] = Vb[d].x; vv[3 * 2 * DX + DX + d] = Vb[d].y;
+                    }
+                    float red2[2 * DX];
+                    row_reduce_scatter<2 * DX>(vv, red2);
+#pragma unroll
+                    for (int e = 0; e < UVS; ++e) o[e] = e < 2 * DX ? red2[e < 2 * DX ? e : 0] : 0.f;
+                    if ((j16 & 3) == 0) {        // one lane per bank: sub-particle i = j16 >> 2 of item 4 r + g
+                        float* dst = uw + (4 * (4 * r + g) + (j16 >> 2)) * UVS;
+#pragma unroll
+                        for (int e = 0; e < UVS; e += 4)
+                            *reinterpret_cast<float4*>(dst + e) = make_float4(o[e], o[e + 1], o[e + 2], o[e + 3]);
+                    }
+                }
+            } else {
             f2 Ua[2][DX], Ub[2][DX], Va[2][DX], Vb[2][DX];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -508,7 +639,8 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
 #pragma unroll
                     for (int jt = 0; jt < JC; ++jt) {
                         float F[DX], W;
-                        read_slot<DX>(cbase + jt * 16 * PS, F, W);
+                        if constexpr (kSplitTile) tile_entry(cur, (c * JC + jt) * 16 + j16, F, W);
+                        else read_slot<DX>(cbase + jt * 16 * PS, F, W);
                         f2 ua[DX], ub[DX], la = f2{W, W}, lb = la;
 #pragma unroll
                         for (int d = 0; d < DX; ++d) {
@@ -625,6 +757,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                         *reinterpret_cast<float4*>(dst + e) = make_float4(o[e], o[e + 1], o[e + 2], o[e + 3]);
                 }
             }
+            }   // (!RO)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -808,7 +941,8 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     for (int i = 0; i < AC::kN; ++i) {
         float v = 0.f;
         if constexpr (kAccLds) {
-            v = accl[i * 64 + lane];
+            if (acc_is_lead(i)) v = lane < kSlotsB ? accB[acc_row(i) * kSlotsB + lane] : 0.f;
+            else v = lane < 32 ? accA[acc_row(i) * 32 + lane] : 0.f;
         } else {
 #pragma unroll
             for (int k = 0; k < AC::kN; ++k) v = (k == i) ? acc[k] : v;
@@ -842,13 +976,14 @@ template <int DX, int DY, int H, int M>
 static int launch_bsim_bwd2(const BsimBwdArgs& a, const BsimBwdOut& o, int jm, hipStream_t stream) {
     using MQ = MlpLds<DX, H, DX, 1>;
     using MG = MlpLds<DX, H, DY, 1>;
-    const int PS = (jm == 3 && DX == 2) ? 20 : BTileSlot<DX>::kFloats;
+    const int PS = (jm == 3 && DX == 2) ? 20 : (DX == 4) ? 5 : BTileSlot<DX>::kFloats;
     constexpr int UVS = (2 * DX + 3) & ~3;
     int cpb, nblk;
     bsim2_geometry(a.N, M, cpb, nblk);
     const int NP = ((a.N + 127) / 128) * 128;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * PS + 4 * (size_t)(DX + 1) * NP +
-                                        4 * (DX + 2) * 32 + 4 * 32 * UVS + 16 + (DX >= 3 ? 4 * (7 * DX + DY) * 64 : 0));
+                                        4 * (DX + 2) * 32 + 4 * 32 * UVS + 16 +
+                                        (DX >= 3 ? 4 * ((2 * DX + DY) * 32 + 5 * DX * 8) : 0));
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
     clear_hip_error();
     if (jm == 3 && DX == 2) {

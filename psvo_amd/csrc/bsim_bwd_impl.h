@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                 if constexpr (HS == 1) {
                     MQ::template eval<kRolled>(wf, x, fmx);
                 } else {
-                    MQ::template eval_part<HS>(wf, hpart, x, fmx);
+                    MQ::template eval_part<HS, ilog2(M)>(wf, hpart, x, fmx);
 #pragma unroll
                     for (int d = 0; d < DX; ++d) fmx[d] += xor_lane<M>(fmx[d]);
                 }
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                     }
                 }
                 if constexpr (HS == 1) MQ::template bwd_input<kRolled>(wf, x, dFo, dxt);
-                else MQ::template bwd_input_part<HS>(wf, hpart, x, dFo, dxt);
+                else MQ::template bwd_input_part<HS, ilog2(M)>(wf, hpart, x, dFo, dxt);
             }
             if (valid && h0) {
 #pragma unroll
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
             if constexpr (HS == 1) {
                 MG::template eval<kRolled>(wg, x, gm);
             } else {
-                MG::template eval_part<HS>(wg, hpart, x, gm);
+                MG::template eval_part<HS, ilog2(M)>(wg, hpart, x, gm);
 #pragma unroll
                 for (int k = 0; k < DY; ++k) gm[k] += xor_lane<M>(gm[k]);
             }
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(256, HS) bsim_bwd_kernel(const BsimBwdArgs a) 
                 if (valid && h0) a.dGt[((tb * DY + k) * N + n) * M + m] = dGo[k];
             }
             if constexpr (HS == 1) MG::template bwd_input<kRolled>(wg, x, dGo, dxt);
-            else MG::template bwd_input_part<HS>(wg, hpart, x, dGo, dxt);
+            else MG::template bwd_input_part<HS, ilog2(M)>(wg, hpart, x, dGo, dxt);
         }
 
         SEC(5);   // MLP_f / MLP_g forward + input gradients, row stores
@@ -632,8 +632,26 @@ __global__ void __launch_bounds__(256) bsim_bwd_fold_finalize(
     const float* __restrict__ dFm_part, const float* __restrict__ dlogW_part, long long TB, int nblk, int N,
     float* __restrict__ dFm, float* __restrict__ dlogW, const float* __restrict__ sacc, int rows, const float* sig_q1inv,
     const float* sig_bq2, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2, float* dsig_init,
-    float* disig) {
+    float* disig, float* __restrict__ dlse, unsigned nfold) {
     using AC = BAcc<DX, DY>;
+    if (blockIdx.x >= nfold && blockIdx.x + 1 < gridDim.x) {
+        // d lse[t, b] = -sum_j d logW^[t, b, j]: the normaliser's share of the filter term's gradient (W^ = logW - lse).  It is
+        // zero analytically (sum_j d W^_j = sum_m d Lambda_m = 0 per chain) and ~1e-7 of the terms in fp32; TF's autodiff --
+        // like any autodiff of the reference's graph -- carries it, and it is what keeps the filter's reverse pass
+        // well-conditioned when the forward particles have left the data range (the softmax-weighted subtraction in
+        // psvo_filter_backward then cancels the common part of d logW_j exactly instead of to 1e-7: measured on
+        // tests/golden/fhn_illconditioned_state.npz, the emission network's gradient error drops 100 x to the fp32 oracle's).
+        // One wave per (t, b) row, straight from the per-workgroup partials, concurrently with the fold blocks.
+        const long long tb = (long long)(blockIdx.x - nfold) * 4 + (threadIdx.x >> 6);
+        if (tb < TB) {
+            const float* p = dlogW_part + tb * nblk * N;
+            float v = 0.f;
+            for (int i = threadIdx.x & 63; i < nblk * N; i += 64) v += p[i];
+            v = wave_sum(v);
+            if ((threadIdx.x & 63) == 0) dlse[tb] = -v;
+        }
+        return;
+    }
     if (blockIdx.x + 1 < gridDim.x) {
         const long long rowF = (long long)DX * N, nF = TB * rowF, nW = TB * N;
         long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -704,15 +722,17 @@ __global__ void __launch_bounds__(256) bsim_bwd_fold_finalize(
 struct BsimBwdOut {
     float *dsig_f, *dsig_g, *dsig_q1inv, *dsig_bq2, *dsig_init, *disig;
     float *dFm, *dlogW;     // folded over the workgroups (the reverse kernels write a.dFm_part / a.dlogW_part)
+    float* dlse;            // (T,B) or NULL: -sum_j d logW (see bsim_bwd_fold_finalize)
 };
 
 template <int DX, int DY>
 static inline void launch_bsim_fold_finalize(const BsimBwdArgs& a, const BsimBwdOut& o, int nblk, hipStream_t stream) {
     const long long TB = (long long)a.T * a.B;
     const long long n = TB * (DX + 1) * a.N / ((a.N & 3) == 0 ? 4 : 1);   // (threads: four outputs each when N % 4 == 0)
-    hipLaunchKernelGGL((bsim_bwd_fold_finalize<DX, DY>), dim3((unsigned)((n + 255) / 256) + 1), dim3(256), 0, stream,
+    const unsigned nfold = (unsigned)((n + 255) / 256), nrow = o.dlse ? (unsigned)((TB + 3) / 4) : 0u;
+    hipLaunchKernelGGL((bsim_bwd_fold_finalize<DX, DY>), dim3(nfold + nrow + 1), dim3(256), 0, stream,
                        a.dFm_part, a.dlogW_part, TB, nblk, a.N, o.dFm, o.dlogW, a.sacc_part, a.B * nblk, a.sig_q1inv,
-                       a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig);
+                       a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig, o.dlse, nfold);
 }
 
 static inline void bsim_geometry(int B, int N, int M, int H, int Dx, int& HS, int& NTB, int& cpb, int& nblk) {

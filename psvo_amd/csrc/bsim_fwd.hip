@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
             if constexpr (HS == 1) {
                 MQ::template eval<kRolled>(wf, x, fmx);
             } else {
-                MQ::template eval_part<HS>(wf, hpart, x, fmx);
+                MQ::template eval_part<HS, ilog2(M)>(wf, hpart, x, fmx);
 #pragma unroll
                 for (int d = 0; d < DX; ++d) fmx[d] += xor_lane<M>(fmx[d]);
             }
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) bsim_fwd_kernel(const BsimArgs a) {
         if constexpr (HS == 1) {
             MG::template eval<kRolled>(wg, x, gm);
         } else {
-            MG::template eval_part<HS>(wg, hpart, x, gm);
+            MG::template eval_part<HS, ilog2(M)>(wg, hpart, x, gm);
 #pragma unroll
             for (int k = 0; k < DY; ++k) gm[k] += xor_lane<M>(gm[k]);
         }
@@ -532,6 +532,7 @@ PSVO_ENTRY(psvo_bsim_forward)(const psvo_desc* desc, const float* X, const float
                                  float* lam2_all, float* om_all, float* mu1_all,
                                  void* stream) {
     using namespace psvo;
+    if (!desc_layers_ok(desc)) return PSVO_ERR_UNSUPPORTED;
 #if PSVO_L == 1
     if (desc && desc->layers == 2)
         return psvo_bsim_forward_l2(desc, X, Fm, logW, lse, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2,

@@ -43,6 +43,10 @@ inline int launch_status() {
     return e == hipSuccess ? PSVO_OK : PSVO_ERR_HIP;
 }
 
+// psvo_desc.layers: 0 or 1 = one hidden layer, 2 = two; anything else (three or more layers, or the garbage an ABI-3 caller's
+// shorter struct leaves there) is refused loudly by every entry point instead of silently running the one-layer kernels
+inline bool desc_layers_ok(const psvo_desc* d) { return !d || (d->layers >= 0 && d->layers <= 2); }
+
 // an MLP argument carries the second hidden layer when this unit is compiled for two (NULL arguments pass: optional MLPs)
 inline bool mlp_layers_ok(const psvo_mlp* m) { return PSVO_L == 1 || !m || (m->Wh && m->bh); }
 
@@ -219,7 +223,8 @@ struct MlpLds<DIN, H, DOUT, 1> {
 
     // Partial evaluation over the hidden units [part*H/S, (part+1)*H/S): S lanes share one MLP
     // evaluation and the caller sums `out` over them (xor-shuffles).  b2 is contributed by part 0.
-    template <int S>
+    // (PB: position of the lane bits that tell the S lanes apart -- used by the two-layer form only)
+    template <int S, int PB = 0>
     __device__ __forceinline__ static void eval_part(const float* __restrict__ w, int part, const float (&x)[DIN],
                                                      float (&out)[DOUT]) {
         constexpr int HP = H / S;
@@ -267,7 +272,7 @@ struct MlpLds<DIN, H, DOUT, 1> {
     }
 
     // dx += partial input gradient over the same hidden slice (caller sums dx over the S lanes)
-    template <int S>
+    template <int S, int PB = 0>
     __device__ __forceinline__ static void bwd_input_part(const float* __restrict__ w, int part, const float (&x)[DIN],
                                                           const float (&dout)[DOUT], float (&dx)[DIN]) {
         constexpr int HP = H / S;
@@ -306,210 +311,261 @@ struct MlpLds<DIN, H, DOUT, 1> {
 // ---------------------------------------------------------------------------------------------
 // Two hidden layers of width H (reference src/transformation/MLP.py:24-38,50-54 with *_layers = "H,H"):
 //     mu = relu(relu(x W1 + b1) Wh + bh) W2 + b2.
-// LDS image: the one-layer image, then Wh[H][H] (keras (in, out), row-major) | bh[H].
-// Same interface as the one-layer struct, so the persistent kernels only carry L as a template parameter.  The first
-// layer (H * DIN FMAs) is evaluated in full by every lane; the H x H layer is walked in groups of four units of the
-// second layer (one wave-uniform float4 of Wh per first-layer unit: 4 FMAs per LDS read), in a rolled loop -- h1 stays
-// in H VGPRs, the reverse pass adds H accumulators for d h1.  With S lanes per evaluation (eval_part / bwd_input_part) a
-// lane owns H / S units of the SECOND layer; the caller sums the outputs / input gradients over the S lanes as before.
+// The H x H layer is the one contraction of the per-particle path with a GEMM shape (K = H = 32 / 64), and it runs on the
+// matrix pipe INSIDE the persistent kernels (round 3; round 2 walked it per lane on the VALU with Wh broadcast from LDS --
+// 4 FMAs per ds_read_b128, LDS-issue-bound: mlp2_valu.h, -DPSVO_L2_VALU).
+//
+// Same interface as the one-layer struct (eval / eval_part<S> / bwd_input / bwd_input_part<S>), so the kernels do not
+// change; what changes is who computes.  The ROWS of a wave -- one per lane, or one per S lanes that hold the same input --
+// are worked on in groups of 16 with the lane mapping of v_mfma_f32_16x16x4_f32 itself: lane = (g, r), g = lane >> 4 the
+// K slot, r = lane & 15 the row of the group.  Lane (g, r) fetches row r's input (ds_bpermute from the lane that owns the
+// row: DIN values), evaluates the H / 4 first-layer units u = 16 q + 4 g + c (q < H / 16, c < 4) of THAT row, and these are
+// the B operands of the product as they stand:
+//     pre2^T[j][r] = sum_k Wh[k][j] h1[r][k]      D[i][r] += A[i][g] B[g][r],  A = WhT[16 jt + i][16 q + 4 g + c]  (LDS),
+//                                                                               B = h1 of row r, unit 16 q + 4 g + c (own register)
+// and the accumulator layout hands lane (g, r) the pre-activations of row r for units 16 jt + 4 g + v -- the same unit set
+// again, so relu, the narrow output layer (partial sums over the lane's H / 4 units, summed over g with two swap-adds),
+// and in the reverse pass  d h1^T[k][r] = sum_j Wh[k][j] d pre2[r][j]  (B = the lane's own d pre2 registers,
+// A = WhT[16 jt + 4 g + v][16 kt + i]) chain without any transposition through LDS.  The result travels back to the
+// row's owner lane with one ds_bpermute per value.  Nothing is stored per particle; the reverse pass recomputes.
+// LDS image: the one-layer image, then WhT[j][k] = Wh[k][j] with rows padded to H + 4 floats (both products then read it
+// with the minimum of two lanes per bank), then bh[H].
+// Cost per group of 16 rows at H = 64: 64 MFMAs (2048 cycles of the matrix pipe = its f32 peak) + 16 ds_read_b128 forward;
+// 128 MFMAs + 16 ds_read_b128 + 64 ds_read_b32 for the input gradient.
 // ---------------------------------------------------------------------------------------------
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int MASK>
+__device__ __forceinline__ float xor_lane(float v);      // (defined with the cross-lane primitives below)
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+__device__ __forceinline__ float lane_fetch(float v, int src_lane) {      // value of `v` in lane src_lane
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+}
+
+#ifdef PSVO_L2_VALU
+#include "mlp2_valu.h"
+#else
 template <int DIN, int H, int DOUT>
 struct MlpLds<DIN, H, DOUT, 2> {
     static constexpr int kW1 = 0;
     static constexpr int kB1 = DIN * H;
     static constexpr int kW2 = kB1 + H;
     static constexpr int kB2 = kW2 + DOUT * H;
-    static constexpr int kWh = kB2 + ((DOUT + 3) & ~3);
-    static constexpr int kBh = kWh + H * H;
+    static constexpr int kWS = H + 4;                          // row stride of the transposed hidden kernel
+    static constexpr int kWh = kB2 + ((DOUT + 3) & ~3);        // WhT[j][k], j = second-layer unit, k = first-layer unit
+    static constexpr int kBh = kWh + H * kWS;
     static constexpr int kSize = kBh + H;
-    static_assert(H % 4 == 0, "hidden width must be a multiple of 4");
+    static constexpr int NQ = H / 16;                          // 16-unit tiles per layer
+    static_assert(H % 16 == 0, "hidden width must be a multiple of 16 (MFMA tile)");
 
     __device__ static void load(float* __restrict__ w, const psvo_mlp& p, int tid, int nthreads) {
         MlpLds<DIN, H, DOUT, 1>::load(w, p, tid, nthreads);
-        for (int i = tid; i < H * H; i += nthreads) w[kWh + i] = p.Wh[i];
+        for (int i = tid; i < H * H; i += nthreads) {
+            const int k = i / H, j = i - k * H;                // Wh is keras (in = k, out = j), row-major
+            w[kWh + j * kWS + k] = p.Wh[i];
+        }
+        for (int i = tid; i < H * (kWS - H); i += nthreads) w[kWh + (i / (kWS - H)) * kWS + H + i % (kWS - H)] = 0.f;
         for (int i = tid; i < H; i += nthreads) w[kBh + i] = p.bh[i];
     }
 
-    // h = relu(x W1 + b1), all H units, kept as H / 2 register pairs (h[2k], h[2k+1]): the H x H layer multiplies by a splat
-    // of one half, which v_pk_fma_f32 takes with op_sel -- a plain float h[] makes hipcc build the {h_i, h_i} pairs with
-    // v_mov and hoist all H of them out of the rolled loop over the second layer (2 H extra registers)
-    __device__ __forceinline__ static void hidden1(const float* __restrict__ w, const float (&x)[DIN], f2 (&h)[H / 2]) {
-        const f2 zero = f2{0.f, 0.f};
+    // rows of a wave: S lanes per row that differ in the lane bits [PB, PB + log2 S); the lane with those bits zero owns it
+    template <int S, int PB>
+    struct Rows {
+        static constexpr int LS = (S == 1) ? 0 : (S == 2) ? 1 : (S == 4) ? 2 : (S == 8) ? 3 : (S == 16) ? 4 : (S == 32) ? 5 : 6;
+        static_assert((1 << LS) == S, "lanes per row: a power of two");
+        static constexpr int NR = 64 / S;                      // rows per wave
+        static constexpr int NG = (NR + 15) / 16;              // groups of 16
+        static constexpr int LOW = (1 << PB) - 1;
+        __device__ __forceinline__ static int row(int lane) { return ((lane >> (PB + LS)) << PB) | (lane & LOW); }
+        __device__ __forceinline__ static int owner(int rho) { return ((rho >> PB) << (PB + LS)) | (rho & LOW); }
+        __device__ __forceinline__ static bool owns(int lane) { return ((lane >> PB) & (S - 1)) == 0; }
+    };
+
+    // pre-activations of the lane's first-layer units u = 16 q + 4 g + c for the row whose input is xr
+    __device__ __forceinline__ static void layer1(const float* __restrict__ w, int g, const float (&xr)[DIN],
+                                                  float (&pre)[NQ][4]) {
 #pragma unroll
-        for (int k = 0; k < H; k += 4) {
-            const float4 b = *reinterpret_cast<const float4*>(w + kB1 + k);
-            f2 ha = f2{b.x, b.y}, hb = f2{b.z, b.w};
+        for (int q = 0; q < NQ; ++q) {
+            const float4 b = *reinterpret_cast<const float4*>(w + kB1 + 16 * q + 4 * g);
+            pre[q][0] = b.x; pre[q][1] = b.y; pre[q][2] = b.z; pre[q][3] = b.w;
 #pragma unroll
-            for (int i = 0; i < DIN; ++i) {
-                const float4 wi = *reinterpret_cast<const float4*>(w + kW1 + i * H + k);
-                const f2 xi = f2{x[i], x[i]};
-                ha = pk_fma(xi, f2{wi.x, wi.y}, ha);
-                hb = pk_fma(xi, f2{wi.z, wi.w}, hb);
+            for (int d = 0; d < DIN; ++d) {
+                const float4 wi = *reinterpret_cast<const float4*>(w + kW1 + d * H + 16 * q + 4 * g);
+                pre[q][0] = fmaf(xr[d], wi.x, pre[q][0]);
+                pre[q][1] = fmaf(xr[d], wi.y, pre[q][1]);
+                pre[q][2] = fmaf(xr[d], wi.z, pre[q][2]);
+                pre[q][3] = fmaf(xr[d], wi.w, pre[q][3]);
             }
-            h[k / 2] = pk_max(ha, zero);
-            h[k / 2 + 1] = pk_max(hb, zero);
         }
     }
 
-    // pre-activations of second-layer units j0 .. j0+3
-    __device__ __forceinline__ static void pre2_group4(const float* __restrict__ w, int j0, const f2 (&h)[H / 2], f2& pa,
-                                                       f2& pb) {
-        const float4 b = *reinterpret_cast<const float4*>(w + kBh + j0);
-        pa = f2{b.x, b.y};
-        pb = f2{b.z, b.w};
-        const float* wh = w + kWh + j0;
+    // D[jt][v] = pre2 of the lane's row, unit 16 jt + 4 g + v (bias included)
+    __device__ __forceinline__ static void hidden2(const float* __restrict__ w, int g, int r, const float (&pre1)[NQ][4],
+                                                   f4v (&D)[NQ]) {
 #pragma unroll
-        for (int i = 0; i < H; i += 2) {
-            const float4 w0 = *reinterpret_cast<const float4*>(wh + i * H);
-            const float4 w1 = *reinterpret_cast<const float4*>(wh + (i + 1) * H);
-            pa = pk_fma_bcast<0>(h[i / 2], f2{w0.x, w0.y}, pa);
-            pb = pk_fma_bcast<0>(h[i / 2], f2{w0.z, w0.w}, pb);
-            pa = pk_fma_bcast<1>(h[i / 2], f2{w1.x, w1.y}, pa);
-            pb = pk_fma_bcast<1>(h[i / 2], f2{w1.z, w1.w}, pb);
-            // (the scheduler otherwise issues all H float4 reads ahead of the FMAs: 4 H registers in flight)
-            if ((i & 7) == 6) __builtin_amdgcn_sched_barrier(0);
+        for (int jt = 0; jt < NQ; ++jt) {
+            const float4 b = *reinterpret_cast<const float4*>(w + kBh + 16 * jt + 4 * g);
+            D[jt] = f4v{b.x, b.y, b.z, b.w};
+        }
+        const float* wa = w + kWh + r * kWS + 4 * g;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float h[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) h[c] = fmaxf(pre1[q][c], 0.f);
+#pragma unroll
+            for (int jt = 0; jt < NQ; ++jt) {
+                const float4 a4 = *reinterpret_cast<const float4*>(wa + 16 * jt * kWS + 16 * q);
+                D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, h[0], D[jt], 0, 0, 0);
+                D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, h[1], D[jt], 0, 0, 0);
+                D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, h[2], D[jt], 0, 0, 0);
+                D[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, h[3], D[jt], 0, 0, 0);
+            }
         }
     }
 
-    // The weights are loop-invariant LDS data of a persistent kernel: left visible, hipcc hoists the (DIN + 1) * H reads of the
-    // first layer of EVERY MLP out of the time loop (fine for one narrow layer; here it is 3 x 192 registers at H = 64 on top
-    // of h and d h: 960 spilled VGPRs in filter_bwd).  An opaque zero offset per call keeps the reads where they are used.
-    // What remains: a result that is only consumed after the NEXT MLP call (dx is the running sum of several calls) has its
-    // tail -- the reads of h and d h -- sunk behind that call's loop, which keeps 2 H registers of every earlier call alive in
-    // it (+230 live values per call at H = 64).  Pinning the results with an `asm volatile("" : "+v"(v))` stops the sinking
-    // (-DPSVO_PIN_RESULTS: 177 registers whatever the number of calls); it is off because these units are built with the
-    // basic register allocator (build.py: L2_FLAGS), where it changes little.
-#if defined(PSVO_PIN_RESULTS)
-    __device__ __forceinline__ static void pin(float& v) { asm volatile("" : "+v"(v)); }
-    __device__ __forceinline__ static void pin_out(float& v) { asm volatile("" : "+v"(v)); }
-#else
-    __device__ __forceinline__ static void pin(float&) {}
-    __device__ __forceinline__ static void pin_out(float&) {}
-#endif
-    __device__ __forceinline__ static const float* opaque(const float* w) {
-        int zo = 0;
-        asm volatile("" : "+v"(zo));
-        return w + zo;
-    }
-
-    template <int HP>
-    __device__ __forceinline__ static void eval_range(const float* __restrict__ w_, int jb, bool bias,
-                                                      const float (&x)[DIN], float (&out)[DOUT]) {
-        const float* w = opaque(w_);
-        f2 h[H / 2];
-        hidden1(w, x, h);
-        f2 acc[DOUT];
+    template <int S, int PB>
+    __device__ __forceinline__ static void eval_rows(const float* __restrict__ w, bool with_bias, const float (&x)[DIN],
+                                                     float (&out)[DOUT]) {
+        using R = Rows<S, PB>;
+        const int lane = __lane_id(), g = lane >> 4, r = lane & 15;
+        const int my_row = R::row(lane);
+        const bool mine = R::owns(lane);
 #pragma unroll
-        for (int o = 0; o < DOUT; ++o) acc[o] = f2{bias ? w[kB2 + o] : 0.f, 0.f};
-        const f2 zero = f2{0.f, 0.f};
+        for (int o = 0; o < DOUT; ++o) out[o] = 0.f;
 #pragma unroll 1
-        for (int jj = 0; jj < HP; jj += 4) {
-            const int j0 = jb + jj;
-            f2 pa, pb;
-            pre2_group4(w, j0, h, pa, pb);
-            pa = pk_max(pa, zero);
-            pb = pk_max(pb, zero);
+        for (int p = 0; p < R::NG; ++p) {
+            const int src = R::owner((16 * p + r) & (R::NR - 1));
+            float xr[DIN];
+#pragma unroll
+            for (int d = 0; d < DIN; ++d) xr[d] = lane_fetch(x[d], src);
+            float pre1[NQ][4];
+            layer1(w, g, xr, pre1);
+            f4v D[NQ];
+            hidden2(w, g, r, pre1, D);
+            float acc[DOUT];
+#pragma unroll
+            for (int o = 0; o < DOUT; ++o) acc[o] = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NQ; ++jt) {
+                const float h0 = fmaxf(D[jt][0], 0.f), h1 = fmaxf(D[jt][1], 0.f), h2 = fmaxf(D[jt][2], 0.f),
+                            h3 = fmaxf(D[jt][3], 0.f);
+#pragma unroll
+                for (int o = 0; o < DOUT; ++o) {
+                    const float4 wo = *reinterpret_cast<const float4*>(w + kW2 + o * H + 16 * jt + 4 * g);
+                    acc[o] = fmaf(h0, wo.x, fmaf(h1, wo.y, fmaf(h2, wo.z, fmaf(h3, wo.w, acc[o]))));
+                }
+            }
 #pragma unroll
             for (int o = 0; o < DOUT; ++o) {
-                const float4 wo = *reinterpret_cast<const float4*>(w + kW2 + o * H + j0);
-                acc[o] = pk_fma(pa, f2{wo.x, wo.y}, acc[o]);
-                acc[o] = pk_fma(pb, f2{wo.z, wo.w}, acc[o]);
+                float v = acc[o];
+                v += xor_lane<16>(v);
+                v += xor_lane<32>(v);                          // every lane (., r) now holds the row's output
+                const float t = lane_fetch(v, my_row & 15);
+                if (mine && (my_row >> 4) == p) out[o] = t + (with_bias ? w[kB2 + o] : 0.f);
             }
         }
+    }
+
+    // dx += (d out / d x)^T dout for the rows of the wave (owner lanes; the other lanes of a row add nothing)
+    template <int S, int PB>
+    __device__ __forceinline__ static void bwd_rows(const float* __restrict__ w, const float (&x)[DIN],
+                                                    const float (&dout)[DOUT], float (&dx)[DIN]) {
+        using R = Rows<S, PB>;
+        const int lane = __lane_id(), g = lane >> 4, r = lane & 15;
+        const int my_row = R::row(lane);
+        const bool mine = R::owns(lane);
+#pragma unroll 1
+        for (int p = 0; p < R::NG; ++p) {
+            const int src = R::owner((16 * p + r) & (R::NR - 1));
+            float xr[DIN], gr[DOUT];
 #pragma unroll
-        for (int o = 0; o < DOUT; ++o) {
-            out[o] = acc[o].x + acc[o].y;
-            pin_out(out[o]);
+            for (int d = 0; d < DIN; ++d) xr[d] = lane_fetch(x[d], src);
+#pragma unroll
+            for (int o = 0; o < DOUT; ++o) gr[o] = lane_fetch(dout[o], src);
+            float pre1[NQ][4];
+            layer1(w, g, xr, pre1);
+            f4v D[NQ];
+            hidden2(w, g, r, pre1, D);
+            // d pre2 of the lane's units: relu'(pre2) * (W2 dout)
+            float dp[NQ][4];
+#pragma unroll
+            for (int jt = 0; jt < NQ; ++jt) {
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < DOUT; ++o) {
+                    const float4 wo = *reinterpret_cast<const float4*>(w + kW2 + o * H + 16 * jt + 4 * g);
+                    s[0] = fmaf(gr[o], wo.x, s[0]); s[1] = fmaf(gr[o], wo.y, s[1]);
+                    s[2] = fmaf(gr[o], wo.z, s[2]); s[3] = fmaf(gr[o], wo.w, s[3]);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dp[jt][v] = D[jt][v] > 0.f ? s[v] : 0.f;
+            }
+            // d h1^T[k][r] = sum_j Wh[k][j] d pre2[r][j]: A = WhT[16 jt + 4 g + v][16 kt + i], B = dp[jt][v]
+            f4v E[NQ];
+#pragma unroll
+            for (int kt = 0; kt < NQ; ++kt) E[kt] = f4v{0.f, 0.f, 0.f, 0.f};
+            const float* wb = w + kWh + 4 * g * kWS + r;
+#pragma unroll
+            for (int jt = 0; jt < NQ; ++jt) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                    for (int kt = 0; kt < NQ; ++kt) {
+                        const float a = wb[(16 * jt + v) * kWS + 16 * kt];
+                        E[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dp[jt][v], E[kt], 0, 0, 0);
+                    }
+                }
+            }
+            // d pre1 = relu'(pre1) d h1;  d x = W1 d pre1 (partial over the lane's units, summed over g)
+            float acc[DIN];
+#pragma unroll
+            for (int d = 0; d < DIN; ++d) acc[d] = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float e[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) e[c] = pre1[q][c] > 0.f ? E[q][c] : 0.f;
+#pragma unroll
+                for (int d = 0; d < DIN; ++d) {
+                    const float4 wi = *reinterpret_cast<const float4*>(w + kW1 + d * H + 16 * q + 4 * g);
+                    acc[d] = fmaf(e[0], wi.x, fmaf(e[1], wi.y, fmaf(e[2], wi.z, fmaf(e[3], wi.w, acc[d]))));
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < DIN; ++d) {
+                float v = acc[d];
+                v += xor_lane<16>(v);
+                v += xor_lane<32>(v);
+                const float t = lane_fetch(v, my_row & 15);
+                if (mine && (my_row >> 4) == p) dx[d] += t;
+            }
         }
     }
 
     template <bool ROLLED = false>
-    __device__ __forceinline__ static void eval(const float* __restrict__ w, const float (&x)[DIN],
-                                                float (&out)[DOUT]) {
-        eval_range<H>(w, 0, true, x, out);
+    __device__ __forceinline__ static void eval(const float* __restrict__ w, const float (&x)[DIN], float (&out)[DOUT]) {
+        eval_rows<1, 0>(w, true, x, out);
     }
-
-    template <int S>
-    __device__ __forceinline__ static void eval_part(const float* __restrict__ w, int part, const float (&x)[DIN],
+    // S lanes (lane bits [PB, PB + log2 S)) hold the same input: the lane with those bits zero receives the whole result,
+    // the others zero -- the caller's sum over the S lanes is unchanged
+    template <int S, int PB = 0>
+    __device__ __forceinline__ static void eval_part(const float* __restrict__ w, int /*part*/, const float (&x)[DIN],
                                                      float (&out)[DOUT]) {
-        constexpr int HP = H / S;
-        static_assert(HP % 4 == 0, "hidden slice must be a multiple of 4");
-        eval_range<HP>(w, part * HP, part == 0, x, out);
+        eval_rows<S, PB>(w, true, x, out);
     }
-
-    // dx += (d out / d x)^T dout through the second-layer units [jb, jb + HP); everything is recomputed
-    template <int HP>
-    __device__ __forceinline__ static void bwd_range(const float* __restrict__ w_, int jb, const float (&x)[DIN],
-                                                     const float (&dout)[DOUT], float (&dx)[DIN]) {
-        const float* w = opaque(w_);
-        f2 h[H / 2];
-        float dh[H];
-        hidden1(w, x, h);
-#pragma unroll
-        for (int i = 0; i < H; ++i) dh[i] = 0.f;
-#pragma unroll 1
-        for (int jj = 0; jj < HP; jj += 4) {
-            const int j0 = jb + jj;
-            f2 pa, pb;
-            pre2_group4(w, j0, h, pa, pb);
-            f2 da = f2{0.f, 0.f}, db = da;
-#pragma unroll
-            for (int o = 0; o < DOUT; ++o) {
-                const float4 wo = *reinterpret_cast<const float4*>(w + kW2 + o * H + j0);
-                const f2 go = f2{dout[o], dout[o]};
-                da = pk_fma(go, f2{wo.x, wo.y}, da);
-                db = pk_fma(go, f2{wo.z, wo.w}, db);
-            }
-            const float d0 = pa.x > 0.f ? da.x : 0.f, d1 = pa.y > 0.f ? da.y : 0.f;
-            const float d2 = pb.x > 0.f ? db.x : 0.f, d3 = pb.y > 0.f ? db.y : 0.f;
-            // (a second read of the four columns of Wh: through the pointer pre2_group4 used, hipcc keeps all 4 H values of its
-            //  reads alive -- in AGPRs at one wave per SIMD, in scratch at two -- instead of re-reading them)
-            const float* wh = opaque(w_) + kWh + j0;
-#pragma unroll
-            for (int i = 0; i < H; ++i) {
-                const float4 wi = *reinterpret_cast<const float4*>(wh + i * H);
-                dh[i] = fmaf(wi.x, d0, fmaf(wi.y, d1, fmaf(wi.z, d2, fmaf(wi.w, d3, dh[i]))));
-                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        f2 dxa[DIN];
-#pragma unroll
-        for (int i = 0; i < DIN; ++i) dxa[i] = f2{dx[i], 0.f};
-        // (W1 is read a second time here: through the same pointer hipcc keeps the DIN * H values of hidden1() in registers
-        //  -- or scratch -- across the loop above instead of re-reading them)
-        const float* wt = opaque(w_);
-#pragma unroll
-        for (int k = 0; k < H; k += 4) {
-            const f2 ga = f2{h[k / 2].x > 0.f ? dh[k] : 0.f, h[k / 2].y > 0.f ? dh[k + 1] : 0.f};
-            const f2 gb = f2{h[k / 2 + 1].x > 0.f ? dh[k + 2] : 0.f, h[k / 2 + 1].y > 0.f ? dh[k + 3] : 0.f};
-#pragma unroll
-            for (int i = 0; i < DIN; ++i) {
-                const float4 wi = *reinterpret_cast<const float4*>(wt + kW1 + i * H + k);
-                dxa[i] = pk_fma(ga, f2{wi.x, wi.y}, dxa[i]);
-                dxa[i] = pk_fma(gb, f2{wi.z, wi.w}, dxa[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < DIN; ++i) {
-            dx[i] = dxa[i].x + dxa[i].y;
-            pin(dx[i]);
-        }
-    }
-
-    template <int S>
-    __device__ __forceinline__ static void bwd_input_part(const float* __restrict__ w, int part, const float (&x)[DIN],
-                                                          const float (&dout)[DOUT], float (&dx)[DIN]) {
-        constexpr int HP = H / S;
-        static_assert(HP % 4 == 0, "hidden slice must be a multiple of 4");
-        bwd_range<HP>(w, part * HP, x, dout, dx);
-    }
-
     template <bool ROLLED = false>
     __device__ __forceinline__ static void bwd_input(const float* __restrict__ w, const float (&x)[DIN],
                                                      const float (&dout)[DOUT], float (&dx)[DIN]) {
-        bwd_range<H>(w, 0, x, dout, dx);
+        bwd_rows<1, 0>(w, x, dout, dx);
+    }
+    template <int S, int PB = 0>
+    __device__ __forceinline__ static void bwd_input_part(const float* __restrict__ w, int /*part*/, const float (&x)[DIN],
+                                                          const float (&dout)[DOUT], float (&dx)[DIN]) {
+        bwd_rows<S, PB>(w, x, dout, dx);
     }
 };
+#endif   // PSVO_L2_VALU
 
 // diagonal-Gaussian log density given inverse scales and the constant -sum(log s) - D/2 log 2pi
 template <int D>

@@ -825,6 +825,7 @@ PSVO_ENTRY(psvo_filter_backward)(
     float* dfm0, float* dsig_q1, float* dsig_q2, float* dsig_f, float* dsig_g, float* dsig0, float* dfsig0,
     float* sacc, void* stream) {
     using namespace psvo;
+    if (!desc_layers_ok(desc)) return PSVO_ERR_UNSUPPORTED;
 #if PSVO_L == 1
     if (desc && desc->layers == 2)
         return psvo_filter_backward_l2(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0,

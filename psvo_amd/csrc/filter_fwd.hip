@@ -622,6 +622,7 @@ PSVO_ENTRY(psvo_filter_forward)(const psvo_desc* desc, const psvo_mlp* q1, const
                                    const float* u, const int32_t* idx_in, float* X, float* Xanc, float* Fm, float* P1,
                                    float* logW, int32_t* idx_out, float* lse, void* stream) {
     using namespace psvo;
+    if (!desc_layers_ok(desc)) return PSVO_ERR_UNSUPPORTED;
 #if PSVO_L == 1
     if (desc && desc->layers == 2)
         return psvo_filter_forward_l2(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0, fm0, fsig0, obs,

@@ -784,6 +784,7 @@ PSVO_ENTRY(psvo_bsimwr_backward)(
     float* dminit_rows, float* dimean_rows, float* dsig_f, float* dsig_g, float* dsig_q1inv, float* dsig_bq2,
     float* dsig_init, float* disig, float* sacc, float* ws, void* stream) {
     using namespace psvo;
+    if (!desc_layers_ok(desc)) return PSVO_ERR_UNSUPPORTED;
 #if PSVO_L == 1
     if (desc && desc->layers == 2)
         return psvo_bsimwr_backward_l2(desc, Fm, logW, lse, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2,

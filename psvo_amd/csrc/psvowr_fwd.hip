@@ -586,6 +586,7 @@ PSVO_ENTRY(psvo_bsimwr_forward)(const psvo_desc* desc, const float* Fm, const fl
                                    float* lseW, int32_t* sel_out, int32_t* anc_out, float* lam2_all, float* om_all,
                                    float* mu1_all, float* ws, void* stream) {
     using namespace psvo;
+    if (!desc_layers_ok(desc)) return PSVO_ERR_UNSUPPORTED;
 #if PSVO_L == 1
     if (desc && desc->layers == 2)
         return psvo_bsimwr_forward_l2(desc, Fm, logW, lse, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bmu2,

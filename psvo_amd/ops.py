@@ -427,10 +427,19 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
     # directly (then no gradient tensor is returned for that MLP), or None
     gb = gbufs or (None, None, None)
 
-    def wgrad():
+    def wgrad(g_stream=None, after=None):
+        """the two or three weight-gradient launches; g_stream: issue MLP_g's on that stream (ordered after the event
+        `after`, i.e. after this kernel's rows exist) beside MLP_q1's on the current one -- the caller joins both"""
         out["gq1"] = mlp_wgrad(filt["X"], out["dP"], q1, Dx, H, Dx, grad=gb[0])
         out["gf"] = None if desc.bootstrap else mlp_wgrad(filt["X"], out["dF"], f, Dx, H, Dx, grad=gb[1])
-        out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy, grad=gb[2])
+        if g_stream is not None and gb[2] is not None:
+            g_stream.wait_event(after)
+            for t in (filt["X"], out["dG"]):
+                t.record_stream(g_stream)
+            with launch_on(g_stream):
+                out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy, grad=gb[2])
+        else:
+            out["gg"] = mlp_wgrad(filt["X"], out["dG"], g, Dx, H, Dy, grad=gb[2])
     if defer_wgrad:          # the caller issues them later (out["_wgrad"]()), e.g. after other writers of the same slices
         out["_wgrad"] = wgrad
         return out
@@ -479,7 +488,7 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
     z = lambda *s: _empty(*s, device=dev)
     out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N),
            "dFm_part": z(T, B, nblk, Dx, N), "dlogW_part": z(T, B, nblk, N), "dFm": z(T, B, Dx, N), "dlogW": z(T, B, N),
-           "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx)}
+           "dlse": z(T, B), "dsig_f": z(Dx), "dsig_g": z(Dy), "dsig_q1inv": z(Dx), "dsig_bq2": z(Dx), "dsig_init": z(Dx), "disig": z(Dx)}
     _chain_rows(out, z, T, B, Dx, N)
     sacc = z(B, nblk, lib.psvo_bsim_acc_size(Dx, Dy))
     _mark("psvo_bsim_backward", 0)
@@ -500,7 +509,7 @@ def bsim_backward(desc, filt, f, g, q1_inv, sig_f, sig_g, sig_q1inv, sig_bq2, bm
     st = lib.psvo_bsim_backward_fold(
         ctypes.byref(desc), _ptr(out["dFm_part"]), _ptr(out["dlogW_part"]), _ptr(sacc), _ptr(sig_q1inv), _ptr(sig_bq2),
         _ptr(out["dFm"]), _ptr(out["dlogW"]), _ptr(out["dsig_f"]), _ptr(out["dsig_g"]), _ptr(out["dsig_q1inv"]),
-        _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _stream())
+        _ptr(out["dsig_bq2"]), _ptr(out["dsig_init"]), _ptr(out["disig"]), _ptr(out["dlse"]), _stream())
     _mark("psvo_bsim_backward_fold", 1)
     _lib.check(st, "psvo_bsim_backward_fold")
     if after_kernel is not None:

@@ -201,3 +201,106 @@ def test_psvowr_weight_closed_form():
     # the cross-chain ancestors really index the selected sub-particles of the same step
     idx = log["idx_r"].unsqueeze(-1).expand(-1, -1, -1, log["bw_Xs"].shape[-1])
     assert torch.equal(log["bw_X_ancestors"], torch.gather(log["bw_Xs"], 1, idx))
+
+
+# ---------------------------------------------------------------------------------------------
+# output_cov and diag_cov: state-dependent diagonal scales (src/transformation/MLP.py:40-46,58-61, src/distribution/mvn.py:66-71)
+# ---------------------------------------------------------------------------------------------
+def test_state_dependent_scale_closed_form_and_scipy():
+    """scale = sigma_con + 0.1 (exp(h W_s + b_s) + 1e-6): log_prob against scipy at two inputs with different scales"""
+    from scipy.stats import norm
+    gen = torch.Generator().manual_seed(5)
+    p = O.make_mlp(gen, 2, [8], 3, 1.0, 0.2, torch.float64, bias_scale=0.3, cov_head=True)
+    d = O.OracleMVN(p)
+    x = torch.randn(4, 2, generator=gen, dtype=torch.float64)
+    y = torch.randn(4, 3, generator=gen, dtype=torch.float64)
+    mu, s = d.mean_and_sigma(x)
+    h = torch.relu(x @ p["layers"][0][0] + p["layers"][0][1])
+    want = torch.nn.functional.softplus(p["sigma_raw"]).clamp(min=0.2) + 0.1 * (torch.exp(h @ p["sigma"][0] + p["sigma"][1]) + 1e-6)
+    assert torch.allclose(s, want) and s.shape == (4, 3) and float((s[0] - s[1]).abs().max()) > 1e-3
+    lp = d.log_prob(x, y)
+    ref = norm.logpdf(y.numpy(), mu.numpy(), s.numpy()).sum(-1)
+    assert np.allclose(lp.numpy(), ref, atol=1e-12)
+    # sample: mean + scale * eps, and its density
+    eps = torch.randn(4, 3, generator=gen, dtype=torch.float64)
+    smp, q = d.sample_and_log_prob(x, eps)
+    assert torch.allclose(smp, mu + s * eps) and np.allclose(q.numpy(), norm.logpdf(eps.numpy()).sum(-1) - np.log(s.numpy()).sum(-1))
+
+
+def test_constant_cov_head_equals_a_larger_state_independent_scale():
+    """a covariance head with a zero kernel adds the constant 0.1 (e^b + 1e-6) to every scale: the model must then equal the
+    plain model whose sigma_con is larger by exactly that -- for every objective, values and ELBO"""
+    for objective in ("AESMC", "PSVO", "PSVOwR"):
+        fl = _flags(objective, n_particles=6, n_particles_for_BSim_proposal=3, output_cov=True, diag_cov=True)
+        P = O.make_params(fl, seed=4, bias_scale=0.2)
+        plain = O.make_params({**fl, "output_cov": False}, seed=4, bias_scale=0.2)
+        for k, v in P.items():
+            if isinstance(v, dict) and "sigma" in v:
+                W, b = v["sigma"]
+                v["sigma"] = (torch.zeros_like(W), b)
+                add = 0.1 * (torch.exp(b) + 1e-6)
+                # softplus(raw) = 5.0067 > sigma_min: shift the clipped scale through sigma_min (max() then picks it)
+                plain[k]["sigma_min"] = None
+                plain[k]["sigma_raw"] = None
+                plain[k]["_scale"] = torch.nn.functional.softplus(v["sigma_raw"]).clamp(min=v["sigma_min"]) + add
+        # (the two parameter sets were drawn from different streams once the heads exist: copy the shared tensors over)
+        def copy(dst, src):
+            for k, v in src.items():
+                if k == "sigma":
+                    continue
+                if isinstance(v, dict):
+                    copy(dst[k], v)
+                elif k not in ("sigma_raw", "sigma_min"):
+                    dst[k] = v
+        copy(plain, P)
+        real = O.get_sigma
+        try:
+            O.get_sigma = lambda p: p["_scale"] if p.get("_scale") is not None else real(p)
+            _, obs = O.fhn_synthetic(2, 5, seed=1)
+            noise = O.make_noise(fl, 2, 5, seed=3)
+            with torch.no_grad():
+                z1, l1 = O.OBJECTIVES[objective](P, fl).get_log_ZSMC(obs, noise)
+                z0, l0 = O.OBJECTIVES[objective](plain, {**fl, "output_cov": False}).get_log_ZSMC(obs, noise)
+        finally:
+            O.get_sigma = real
+        assert abs(float(z1) - float(z0)) < 1e-10 * abs(float(z0)), (objective, float(z1), float(z0))
+        assert torch.allclose(l1["Xs"], l0["Xs"], atol=1e-12)
+
+
+@pytest.mark.parametrize("objective", ["AESMC", "SVO", "PSVO"])
+def test_state_dependent_scale_autograd_matches_finite_differences(objective):
+    fl = _flags(objective, n_particles=5, n_particles_for_BSim_proposal=3, output_cov=True, diag_cov=True)
+    Oracle = O.OBJECTIVES[objective]
+    P = O.make_params(fl, seed=2, bias_scale=0.3)
+    for k in P:
+        if isinstance(P[k], dict) and "sigma_raw" in P[k]:
+            P[k]["sigma_raw"] = torch.full_like(P[k]["sigma_raw"], 1.0)
+            P[k]["sigma_min"] = 0.2
+            W, b = P[k]["sigma"]
+            P[k]["sigma"] = (0.3 * W, b)          # (he_normal kernels through exp(): keep the scales O(1))
+    _, obs = O.fhn_synthetic(2, 4, seed=3)
+    noise = O.make_noise(fl, 2, 4, seed=8)
+    with torch.no_grad():
+        _, log = Oracle(P, fl).get_log_ZSMC(obs, noise)
+    teacher = {**noise, "idx_f": log["idx_f"]}
+    if objective == "PSVO":
+        teacher["idx_b"] = log["idx_b"]
+    targets = [P["q1"]["sigma"][0], P["g"]["sigma"][1], P["q1"]["layers"][0][0], P["q2"]["sigma"][0], P["q0"]["sigma_raw"]]
+    if objective == "PSVO":
+        targets += [P["q1_inv"]["sigma"][0], P["BSim_q2"]["sigma"][1]]
+    for t in targets:
+        t.requires_grad_(True)
+    z, _ = Oracle(P, fl).get_log_ZSMC(obs, teacher)
+    grads = torch.autograd.grad(z, targets)
+    for t, g in zip(targets, grads):
+        flat = t.detach().view(-1)
+        for k in (0, flat.numel() // 2):
+            old = float(flat[k])
+            with torch.no_grad():
+                flat[k] = old + 1e-6
+                zp, _ = Oracle(P, fl).get_log_ZSMC(obs, teacher)
+                flat[k] = old - 1e-6
+                zm, _ = Oracle(P, fl).get_log_ZSMC(obs, teacher)
+                flat[k] = old
+            fd = (float(zp) - float(zm)) / 2e-6
+            assert abs(fd - float(g.view(-1)[k])) < 2e-5 * max(1.0, abs(fd)), (objective, fd, float(g.view(-1)[k]))

@@ -26,7 +26,16 @@ ARMS = {
     "psvo+padded+overlap+flat": dict(extra=dict(q1_layers="24", g_layers="16"), overlap=1, flat=1),
     "psvo+padded+overlap+noflat": dict(extra=dict(q1_layers="24", g_layers="16"), overlap=1, flat=0),
     "psvowr+overlap+noflat": dict(obj="PSVOwR", extra={}, overlap=1, flat=0),
+    # the trainer's wiring: streams joined by the caller after backward() (autograd.deferred_join)
+    "psvo+deferred": dict(extra={}, overlap=1, flat=1, deferred=1),
+    # ... with the filter's MLP_g weight gradient on the second side stream (PSVO_FILTER_WGRAD_SPLIT)
+    "psvo+deferred+gsplit": dict(extra={}, overlap=1, flat=1, deferred=1, gsplit=1),
 }
+# NOT part of run_all(): the round-2 abort reproduced on purpose.  Two streams forked into one capture that wait on EACH
+# OTHER's events (side waits for the backward simulation's weight gradients on side2; side2 waits for the filter's reverse
+# kernel on side) are a DAG of work but a cycle in the runtime's fork relation, and hip::Stream::EndCapture (ROCm 7.2) walks
+# that relation recursively without a visited set: stack overflow, SIGSEGV.  `python tools/capture_probe.py psvo+cross-wait`
+NEGATIVE = {"psvo+cross-wait": dict(extra={}, overlap=1, flat=1, deferred=1, gsplit=1, cross=1)}
 
 
 def arm(name):
@@ -37,8 +46,10 @@ def arm(name):
     from psvo_amd import autograd
     from psvo_amd.graph import GraphedStep
     from psvo_amd.optim import FlatParams
-    a = ARMS[name]
+    a = ARMS.get(name) or NEGATIVE[name]
     autograd.OVERLAP = bool(a["overlap"])
+    autograd.SPLIT_FILTER_WGRAD = bool(a.get("gsplit"))
+    autograd.SPLIT_CROSS_WAIT = bool(a.get("cross"))
     obj = a.get("obj", "PSVO")
     FLAGS, model, smc, obs, noise = TP._setup(obj, 2, 8, 16, 8 if obj.startswith("PSVO") else 1, 2, 1, 32, True, True,
                                               seed=4, **a["extra"])
@@ -52,7 +63,11 @@ def arm(name):
         else:
             model.zero_grad(set_to_none=False)
         z, _ = smc.get_log_ZSMC(obs_c, None, noise=nz)
-        z.backward()
+        if a.get("deferred"):
+            with autograd.deferred_join():
+                z.backward()
+        else:
+            z.backward()
         return z.detach()
     z_e = local().clone()            # eager, on the null stream
     torch.cuda.synchronize()

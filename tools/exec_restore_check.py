@@ -7,8 +7,10 @@ AHEAD of the `s_or_b64 exec, exec, s[..]` that ends the `if`.  The copies then r
 that skipped the `if` keep a stale AGPR and read it back later under full EXEC.  psvowr_bwd_kernel<3,1,64,4,256> (two hidden
 layers) lost part of its sigma_g sum that way.  This tool makes the pattern visible for every kernel of the library:
 
-    for every `s_and_saveexec_b64 sX, ..` + `s_cbranch_execz T` it lists the vector instructions between the skip target T
-    and the `s_or_b64 exec, exec, sX` that ends that `if`.  Normally T IS the restore.  Register copies found there
+    for every `s_and_saveexec_b64 sX, ..` + `s_cbranch_execz T` -- and, since round 3, every `s_xor_b64 exec, exec, sX` +
+    `s_cbranch_execz T`, the `else` arm of a diamond (hipcc turns `acc += cond ? v : 0` into one: zero in the flow block, v in
+    the else body; bsim_bwd_kernel<4,2,64,4,16,1> lost d = 3 of two scale sums that way) -- it lists the vector instructions
+    between the skip target T and the `s_or_b64 exec, exec, sX` that ends that region.  Normally T IS the restore.  Register copies found there
     (v_accvgpr_write / v_accvgpr_read / v_mov / scratch stores and loads: what a live-range split or a spill inserts) are
     class A -- the failure above -- and make the exit code 1; other vector instructions there are the tail of the `if` body
     (address arithmetic of a divergent loop, for example: they run for the active lanes only either way) and are listed as
@@ -80,10 +82,17 @@ def check(body):
     for i, (a, op, args) in enumerate(body):
         if op != "s_cbranch_execz" or i + 1 >= len(body):
             continue
+        # the instruction that set EXEC for the region this branch skips: `s_and_saveexec_b64 sX, ..` (the `then` arm),
+        # or -- the `else` arm of an if / else diamond, found in round 3 -- `s_xor_b64 exec, exec, sX` behind the
+        # `s_or_saveexec_b64 sX, sX` of the flow block: the region then ends at `s_or_b64 exec, exec, sX` all the same
         saved = None
         for j in range(i - 1, max(-1, i - 4), -1):
-            if body[j][1] in ("s_and_saveexec_b64", "s_or_saveexec_b64"):
+            opj, argj = body[j][1], body[j][2].replace(" ", "")
+            if opj in ("s_and_saveexec_b64", "s_or_saveexec_b64"):
                 saved = body[j][2].split(",")[0].strip()
+                break
+            if opj == "s_xor_b64" and argj.startswith("exec,exec,"):
+                saved = argj[len("exec,exec,"):]
                 break
         if saved is None:
             continue
@@ -167,12 +176,8 @@ def scan(objs, verbose=True):
 
 def main(objs):
     n, rows = scan(objs)
-    # (psvo::l2 = the two-hidden-layer units, built with -vgpr-regalloc=basic: stores after definitions and reloads before
-    #  uses inside divergent regions are that allocator's normal, lane-exact spill code -- counted apart, not failed on)
-    l2 = sum(1 for r in rows if r[2] and "4psvo2l2" in r[1])
-    a = sum(1 for r in rows if r[2]) - l2
-    print("kernels scanned: %d, class A: %d (+ %d in psvo::l2, basic allocator), class B only: %d"
-          % (n, a, l2, len(rows) - a - l2))
+    a = sum(1 for r in rows if r[2])
+    print("kernels scanned: %d, class A: %d, class B only: %d" % (n, a, len(rows) - a))
     return 1 if a else 0
 
 
