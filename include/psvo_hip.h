@@ -100,6 +100,13 @@ const char* psvo_status_string(int status);
 /*   PSVO_TUNE_ROWS_BWD: rows per workgroup of psvo_rows_mlp_backward: 0 = chosen by the number of rows (default), 16, 64.
  *     It changes psvo_rows_mlp_blocks(): set it before sizing workspaces. */
 #define PSVO_TUNE_ROWS_BWD 2
+/*   PSVO_TUNE_L2_SPLIT: two-hidden-layer builds of psvo_bsim_forward / _backward: 0 (default) one lane per (chain, m);
+ *   1 = a chain spread over 2 M lanes for small problems, as the one-layer builds do.  Set before sizing buffers. */
+#define PSVO_TUNE_L2_SPLIT 3
+/*   PSVO_TUNE_SKEW: start-up phase offset between the workgroups that share a CU in the backward-simulation kernels, in
+ *   per cent of the kernel's estimate of its pair-phase length (default 0 = all workgroups start together: measured, it
+ *   changes nothing -- profiles/r03_bsim_bwd_C5_ab.md -- and is kept as an A/B knob). */
+#define PSVO_TUNE_SKEW 4
 int psvo_set_tuning(int key, int value);          /* PSVO_OK or PSVO_ERR_INVALID */
 int psvo_get_tuning(int key);
 

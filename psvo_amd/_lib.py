@@ -15,6 +15,8 @@ PSVO_ERR_UNSUPPORTED = -2
 PSVO_ERR_HIP = -3
 PSVO_TUNE_BSIM_BWD = 1      # psvo_set_tuning keys (include/psvo_hip.h)
 PSVO_TUNE_ROWS_BWD = 2
+PSVO_TUNE_L2_SPLIT = 3
+PSVO_TUNE_SKEW = 4
 
 
 class PsvoHipError(RuntimeError):
@@ -108,6 +110,12 @@ def load():
         v = os.environ.get("PSVO_BSIM_BWD_VARIANT")      # A/B measurements (tools/, bench.py --bsim-bwd-variant)
         if v is not None and lib.psvo_set_tuning(PSVO_TUNE_BSIM_BWD, int(v)) != PSVO_OK:
             raise PsvoHipError("PSVO_BSIM_BWD_VARIANT=%s is not a valid psvo_set_tuning value" % v)
+        v = os.environ.get("PSVO_SKEW")                  # A/B: phase offset of co-resident workgroups, per cent (0 = off)
+        if v is not None and lib.psvo_set_tuning(PSVO_TUNE_SKEW, int(v)) != PSVO_OK:
+            raise PsvoHipError("PSVO_SKEW=%s is not a valid psvo_set_tuning value" % v)
+        v = os.environ.get("PSVO_L2_SPLIT")              # A/B: two-layer backward-simulation kernels with the half-split chains
+        if v is not None and lib.psvo_set_tuning(PSVO_TUNE_L2_SPLIT, int(v)) != PSVO_OK:
+            raise PsvoHipError("PSVO_L2_SPLIT=%s is not a valid psvo_set_tuning value" % v)
         _lib = lib
     return _lib
 

@@ -41,8 +41,18 @@ int set_rows_bwd_rb(int v);     // rows_mlp.hip
 int get_rows_bwd_rb();
 }  // namespace psvo
 
+namespace psvo { int g_tune_l2_split = 0; int g_tune_skew_pct = 0; }
+
 extern "C" int psvo_set_tuning(int key, int value) {
     if (key == PSVO_TUNE_ROWS_BWD) return psvo::set_rows_bwd_rb(value);
+    if (key == PSVO_TUNE_SKEW && value >= 0 && value <= 1000) {
+        psvo::g_tune_skew_pct = value;
+        return PSVO_OK;
+    }
+    if (key == PSVO_TUNE_L2_SPLIT && (value == 0 || value == 1)) {
+        psvo::g_tune_l2_split = value;
+        return PSVO_OK;
+    }
     if (key == PSVO_TUNE_BSIM_BWD && value >= -1 && value <= 4) {
         g_bsim_bwd_variant = value;
         return PSVO_OK;
@@ -52,6 +62,8 @@ extern "C" int psvo_set_tuning(int key, int value) {
 
 extern "C" int psvo_get_tuning(int key) {
     if (key == PSVO_TUNE_ROWS_BWD) return psvo::get_rows_bwd_rb();
+    if (key == PSVO_TUNE_L2_SPLIT) return psvo::g_tune_l2_split;
+    if (key == PSVO_TUNE_SKEW) return psvo::g_tune_skew_pct;
     return key == PSVO_TUNE_BSIM_BWD ? g_bsim_bwd_variant : PSVO_ERR_INVALID;
 }
 
@@ -61,7 +73,7 @@ extern "C" int psvo_bsim_blocks(const psvo_desc* desc) {
     int HS, NTB, cpb, nblk;
     if (bsim_bwd_variant(desc->B, desc->T, desc->N, desc->M, desc->Dx, desc->Dy, desc->layers) != 0)
         psvo::bsim2_geometry(desc->N, desc->M, cpb, nblk);
-    else psvo::bsim_geometry(desc->B, desc->N, desc->M, desc->H, desc->Dx, HS, NTB, cpb, nblk);
+    else psvo::bsim_geometry(desc->B, desc->N, desc->M, desc->H, desc->Dx, HS, NTB, cpb, nblk, desc->layers == 2 ? 2 : 1);
     return nblk;
 }
 
@@ -85,6 +97,7 @@ extern "C" int psvo_bsim_backward(
     if (desc->N > 1024 || desc->B > 65535 || !desc_layers_ok(desc)) return PSVO_ERR_UNSUPPORTED;
 
     BsimBwdArgs a;
+    a.skew = 0;
     a.B = desc->B; a.T = desc->T; a.N = desc->N; a.emission = desc->emission;
     a.f = *f; a.g = *g; a.q1inv = *q1_inv;
     a.Fm = Fm; a.logW = logW; a.lse = lse;

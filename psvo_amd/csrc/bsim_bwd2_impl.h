@@ -156,13 +156,17 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     constexpr int UVS = (2 * DX + 3) & ~3;   // floats per (chain, m) of the U / V hand-back, padded to float4s
     // forward-particle tiles (of 16) per chunk whose per-j sums live in registers (the MFMA accumulators take four
     // registers per tile where the VALU form takes NA: half the tiles per chunk keep it inside the 256-VGPR budget)
-    constexpr int JC = (JM || DX >= 3) ? 4 : 8;   // (Dx >= 3: register budget)
-    // RO ("rounds outer", Dx >= 3, round 3): the two rounds of items of a lane group are walked one after the other over the
+    // (Dx >= 3: register budget.  Dx = 4: TWO tiles per chunk -- the unrolled pair arithmetic of a tile takes ~20 registers at
+    //  Dx = 4; with four tiles in flight the kernel spilled 88 registers around the pair phase, ~45 KB of scratch traffic per
+    //  wave and step, and that traffic, not the ALU, set its pace at C5 (44.5 ms); with eight: 357.)
+    constexpr int JC = (JM == 0 && DX == 4) ? 2 : (JM || DX >= 3) ? 4 : 8;
+    // RO ("rounds outer", Dx = 4, round 3): the two rounds of items of a lane group are walked one after the other over the
     // WHOLE tile instead of inside every chunk, so only one round's U / V sums (8 Dx registers, not 16 Dx) are live; the
     // per-j sums of a chunk are then flushed once per (round, chunk) and round 1 ADDS to round 0's value in the wave's LDS
     // copy (same lane, same address: ordered).  With the other register savings below this is what lets the Dx = 4 kernel run
     // two waves per SIMD without scratch.
-    constexpr bool RO = (DX >= 3) && (JM == 0);
+    // (Dx = 3 fits both rounds with chunks of four tiles and measured 5 % faster that way: C3 4.76 against 5.02 ms.)
+    constexpr bool RO = (DX == 4) && (JM == 0);
     // Dx = 4, VALU form: the tile is kept as F'[NP] (float4) + W'[NP] (float) -- 20 B per forward particle instead of the
     // 32 B of the padded slot -- so that two workgroups fit a CU's LDS at N = 512 (C5)
     constexpr bool kSplitTile = (DX == 4) && (JM == 0);
@@ -299,24 +303,35 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
             read_slot<DX>(buf + j * PS, F, W);
         }
     };
-    auto get_slot = [&](int tt, int j, float (&raw)[DX + 1]) {
+    static_assert(offsetof(BsimBwdArgs, logW) - offsetof(BsimBwdArgs, Fm) == 8 &&
+                  offsetof(BsimBwdArgs, lse) - offsetof(BsimBwdArgs, Fm) == 16 && offsetof(BsimBwdArgs, Fm) % 32 == 0,
+                  "BsimBwdArgs: forward-tile pointer block");
+    auto get_slot = [&](int tt, int j, float (&raw)[DX + 1], const float* Fm, const float* logW) {
         const unsigned tb = (unsigned)tt * B + b;
         const unsigned jc = j < N ? j : N - 1;
-        const float* Fm = PSVO_ARG(BsimBwdArgs, Fm);
 #pragma unroll
         for (int d = 0; d < DX; ++d) raw[d] = ldf(Fm, 4u * ((tb * DX + d) * N + jc));
-        raw[DX] = ldf(PSVO_ARG(BsimBwdArgs, logW), 4u * (tb * N + jc));
+        raw[DX] = ldf(logW, 4u * (tb * N + jc));
     };
+    // (a second entry per thread travels through registers too when the tile has more than 256: N = 512, C5 -- copied at store
+    //  time it cost an exposed round trip to memory per step)
+    float st2[DX + 1];
+    const bool two_slots = (DX >= 3) && NP > NTB;      // (Dx = 2 is at its register budget: kept as it was)
     auto stage_load = [&](int tt) {
+        unsigned long long pt[4];
+        arg_block<4>((unsigned)offsetof(BsimBwdArgs, Fm), pt);     // Fm, logW, lse (, sig_f)
         st_t = tt;
-        st_l = ldf(PSVO_ARG(BsimBwdArgs, lse), 4u * ((unsigned)tt * B + b));
-        if (tid < NP) get_slot(tt, tid, st);
+        st_l = ldf(reinterpret_cast<const float*>(pt[2]), 4u * ((unsigned)tt * B + b));
+        if (tid < NP) get_slot(tt, tid, st, reinterpret_cast<const float*>(pt[0]), reinterpret_cast<const float*>(pt[1]));
+        if (two_slots && tid + NTB < NP)
+            get_slot(tt, tid + NTB, st2, reinterpret_cast<const float*>(pt[0]), reinterpret_cast<const float*>(pt[1]));
     };
     auto stage_store = [&](float* buf) {
         if (tid < NP) put_slot(buf, tid, st, st_l);
-        for (int j = tid + NTB; j < NP; j += NTB) {
+        if (two_slots && tid + NTB < NP) put_slot(buf, tid + NTB, st2, st_l);
+        for (int j = tid + (two_slots ? 2 : 1) * NTB; j < NP; j += NTB) {
             float raw[DX + 1];
-            get_slot(st_t, j, raw);
+            get_slot(st_t, j, raw, PSVO_ARG(BsimBwdArgs, Fm), PSVO_ARG(BsimBwdArgs, logW));
             put_slot(buf, j, raw, st_l);
         }
     };
@@ -367,19 +382,38 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
         float eps[DX], bm[DX], xp[DX], mu1[DX], y[DY], om, lam2;
         int sel;
     };
+    // obs, eps_b, bwX, sel, lam2_all, om_all, mu1_all (, dscore) are adjacent in BsimBwdArgs: one s_load_dwordx16 for the seven
+    // base pointers of a step's inputs instead of seven dependent scalar loads (common.h: arg_block)
+    static_assert(offsetof(BsimBwdArgs, dscore) - offsetof(BsimBwdArgs, obs) == 56 && offsetof(BsimBwdArgs, obs) % 64 == 0 &&
+                  offsetof(BsimBwdArgs, eps_b) - offsetof(BsimBwdArgs, obs) == 8 &&
+                  offsetof(BsimBwdArgs, bwX) - offsetof(BsimBwdArgs, obs) == 16 &&
+                  offsetof(BsimBwdArgs, sel) - offsetof(BsimBwdArgs, obs) == 24 &&
+                  offsetof(BsimBwdArgs, lam2_all) - offsetof(BsimBwdArgs, obs) == 32 &&
+                  offsetof(BsimBwdArgs, om_all) - offsetof(BsimBwdArgs, obs) == 40 &&
+                  offsetof(BsimBwdArgs, mu1_all) - offsetof(BsimBwdArgs, obs) == 48, "BsimBwdArgs: input pointer block");
     auto load_step = [&](bool lst, bool fst, StepIn& s) {    // (the offsets already point at the step to load)
-        s.sel = ldi(PSVO_ARG(BsimBwdArgs, sel), o_n);
+        unsigned long long pb[8];
+        arg_block<8>((unsigned)offsetof(BsimBwdArgs, obs), pb);
+        const float* const p_obs = reinterpret_cast<const float*>(pb[0]);
+        const float* const p_eps = reinterpret_cast<const float*>(pb[1]);
+        const float* const p_bwX = reinterpret_cast<const float*>(pb[2]);
+        const int32_t* const p_sel = reinterpret_cast<const int32_t*>(pb[3]);
+        const float* const p_lam2 = reinterpret_cast<const float*>(pb[4]);
+        const float* const p_om = reinterpret_cast<const float*>(pb[5]);
+        const float* const p_mu1 = reinterpret_cast<const float*>(pb[6]);
+        const float* const p_bm = PSVO_ARG(BsimBwdArgs, bmu2);
+        s.sel = ldi(p_sel, o_n);
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            s.eps[d] = ldf(PSVO_ARG(BsimBwdArgs, eps_b), o_dnm[d]);
-            s.bm[d] = ldf(PSVO_ARG(BsimBwdArgs, bmu2), o_d + 4u * d);
-            s.xp[d] = lst ? 0.f : ldf(PSVO_ARG(BsimBwdArgs, bwX), o_dn[d] + s_dn);
-            s.mu1[d] = lst ? 0.f : ldf(PSVO_ARG(BsimBwdArgs, mu1_all), o_dn[d]);
+            s.eps[d] = ldf(p_eps, o_dnm[d]);
+            s.bm[d] = ldf(p_bm, o_d + 4u * d);
+            s.xp[d] = lst ? 0.f : ldf(p_bwX, o_dn[d] + s_dn);
+            s.mu1[d] = lst ? 0.f : ldf(p_mu1, o_dn[d]);
         }
 #pragma unroll
-        for (int k = 0; k < DY; ++k) s.y[k] = ldf(PSVO_ARG(BsimBwdArgs, obs), o_k + 4u * k);
-        s.om = ldf(PSVO_ARG(BsimBwdArgs, om_all), o_nm);
-        s.lam2 = fst ? 0.f : ldf(PSVO_ARG(BsimBwdArgs, lam2_all), o_nm);
+        for (int k = 0; k < DY; ++k) s.y[k] = ldf(p_obs, o_k + 4u * k);
+        s.om = ldf(p_om, o_nm);
+        s.lam2 = fst ? 0.f : ldf(p_lam2, o_nm);
     };
     auto advance = [&]() {
         o_nm += s_nm; o_n += s_n; o_d += s_d; o_k += s_k;
@@ -391,13 +425,17 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
     StepIn cur_in, nxt_in;
     load_step(T == 1, true, cur_in);
 
+    phase_skew(a.skew);
     SEC_INIT(bsim_bwd2)
     for (int t = 0; t < T; ++t) {
         SEC(0);
         const bool first = (t == 0), last = (t == T - 1);
         const float* cur = tile + ((t + 1) & 1) * NP * PS;  // tile(t-1), valid for t >= 1
         float* nxt = tile + (t & 1) * NP * PS;              // tile(t) for step t+1
-        if (t + 1 < T && t >= 1) stage_load(t);
+        // (Dx = 4: the next tile's entries are requested behind the pair phase, like the next step's inputs -- the registers
+        //  they land in would be live across it; the MLP phase and the chain reductions still cover the latency)
+        constexpr bool kLateTile = (DX == 4);
+        if (!kLateTile && t + 1 < T && t >= 1) stage_load(t);
         // the offsets are advanced to step t+1 for the prefetch; this step's stores subtract the stride again
         advance();
         // Dx <= 2: the next step's inputs are requested here, a whole step ahead.  Dx >= 3: only after the pair phase (the
@@ -502,21 +540,16 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                             }
                         }
                         // flush: reduce over the four lane groups, one owner lane per (j, e); round 1 adds to round 0's value
+                        static_assert(JC == 2, "rounds-outer flush: two tiles per chunk");
+                        // lane bit 5 keeps tile 0 (groups 0, 1) or tile 1 (groups 2, 3); lane bit 4 is then summed out and
+                        // the even group of each pair owns the tile
 #pragma unroll
-                        for (int jt = 0; jt < JC / 2; ++jt)
-#pragma unroll
-                            for (int e = 0; e < NA; ++e) A2[jt][e] = swap_add32(A2[jt][e], A2[jt + JC / 2][e]);
-#pragma unroll
-                        for (int jt = 0; jt < JC / 4; ++jt)
-#pragma unroll
-                            for (int e = 0; e < NA; ++e) A2[jt][e] = swap_add16(A2[jt][e], A2[jt + JC / 4][e]);
-                        const int jt0 = (JC / 2) * (g >> 1) + (JC / 4) * (g & 1);
-#pragma unroll
-                        for (int jt = 0; jt < JC / 4; ++jt) {
-#pragma unroll
-                            for (int e = 0; e < NA; ++e) {
-                                float* dst = ja + e * NP + (c * JC + jt0 + jt) * 16 + j16;
-                                *dst = (r == 0) ? A2[jt][e] : *dst + A2[jt][e];
+                        for (int e = 0; e < NA; ++e) {
+                            float v = swap_add32(A2[0][e], A2[1][e]);
+                            v += xor_lane<16>(v);
+                            if ((g & 1) == 0) {
+                                float* dst = ja + e * NP + (c * JC + (g >> 1)) * 16 + j16;
+                                *dst = (r == 0) ? v : *dst + v;
                             }
                         }
                     }
@@ -798,6 +831,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
         }
 
         if (kLatePrefetch && t + 1 < T) load_step(t + 2 == T, false, nxt_in);
+        if (kLateTile && t + 1 < T && t >= 1) stage_load(t);
         SEC(4);   // hand-back
         // ---- f(x_{t+1} | x~), g(y_t | x~) ------------------------------------------------------------------------
         float dxp_part[DX];
@@ -823,11 +857,17 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                 }
                 MQ::template bwd_input_part<PART>(wf, part, x, dFo, dxt);
             }
+            static_assert(offsetof(BsimBwdArgs, dFt) - offsetof(BsimBwdArgs, xt) == 8 &&
+                          offsetof(BsimBwdArgs, dGt) - offsetof(BsimBwdArgs, xt) == 16 &&
+                          offsetof(BsimBwdArgs, dmu1) - offsetof(BsimBwdArgs, xt) == 24 && offsetof(BsimBwdArgs, xt) % 32 == 0,
+                          "BsimBwdArgs: row pointer block");
+            unsigned long long pr[4];
+            arg_block<4>((unsigned)offsetof(BsimBwdArgs, xt), pr);       // xt, dFt, dGt, dmu1
             if (srow) {
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
-                    stf(PSVO_ARG(BsimBwdArgs, dFt), o_dnm[d] - s_dnm, dFo[d]);
-                    stf(PSVO_ARG(BsimBwdArgs, xt), o_dnm[d] - s_dnm, x[d]);
+                    stf(reinterpret_cast<float*>(pr[1]), o_dnm[d] - s_dnm, dFo[d]);
+                    stf(reinterpret_cast<float*>(pr[0]), o_dnm[d] - s_dnm, x[d]);
                 }
             }
             float gm[DY], dGo[DY];
@@ -841,7 +881,7 @@ __global__ void __launch_bounds__(256, 2) bsim_bwd2_kernel(const BsimBwdArgs a) 
                 const float z = (y[k] - gm[k]) * isg[k];
                 dGo[k] = dphi * z * isg[k] * dmean;
                 if (h0) acc_add(AC::kSg + k, dphi * (z * z - 1.f) * isg[k]);
-                if (srow) stf(PSVO_ARG(BsimBwdArgs, dGt), o_knm[k] - s_knm, dGo[k]);
+                if (srow) stf(reinterpret_cast<float*>(pr[2]), o_knm[k] - s_knm, dGo[k]);
             }
             MG::template bwd_input_part<PART>(wg, part, x, dGo, dxt);
         }
@@ -985,18 +1025,21 @@ static int launch_bsim_bwd2(const BsimBwdArgs& a, const BsimBwdOut& o, int jm, h
                                         4 * (DX + 2) * 32 + 4 * 32 * UVS + 16 +
                                         (DX >= 3 ? 4 * ((2 * DX + DY) * 32 + 5 * DX * 8) : 0));
     if (lds > 160 * 1024) return PSVO_ERR_UNSUPPORTED;
+    // pair phase of one wave, alone on its SIMD: 2560 cycles at N = 128, Dx = 2 (section timers), ~ N (3 Dx + 4)
+    BsimBwdArgs as = a;
+    as.skew = (int)(2560.0 * NP / 128.0 * (3 * DX + 4) / 10.0 * g_tune_skew_pct / 100.0);
     clear_hip_error();
     if (jm == 3 && DX == 2) {
         if constexpr (DX == 2)
-            hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 3>), dim3(nblk, a.B), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 3>), dim3(nblk, a.B), dim3(256), lds, stream, as);
     } else if (jm == 2 && DX == 2) {
         if constexpr (DX == 2)
-            hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 2>), dim3(nblk, a.B), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 2>), dim3(nblk, a.B), dim3(256), lds, stream, as);
     } else if (jm == 1 && DX == 2) {
         if constexpr (DX == 2)       // (A/B arm only: not instantiated for the shapes whose default is v1)
-            hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 1>), dim3(nblk, a.B), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 1>), dim3(nblk, a.B), dim3(256), lds, stream, as);
     } else {
-        hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 0>), dim3(nblk, a.B), dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((bsim_bwd2_kernel<DX, DY, H, M, 0>), dim3(nblk, a.B), dim3(256), lds, stream, as);
     }
     (void)o;
     return launch_status();

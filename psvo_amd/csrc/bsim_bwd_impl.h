@@ -45,6 +45,7 @@ struct BsimBwdArgs {
     const float* dscore;  // (B,N)
     float *xt, *dFt, *dGt, *dmu1;
     float *dFm_part, *dlogW_part, *dbmu2_rows, *dminit_rows, *dimean_rows, *sacc_part;
+    int skew;        // phase offset (shader-clock cycles) of every other resident workgroup: common.h, phase_skew()
 };
 
 template <int DX, int DY>
@@ -735,12 +736,12 @@ static inline void launch_bsim_fold_finalize(const BsimBwdArgs& a, const BsimBwd
                        a.sig_bq2, o.dsig_f, o.dsig_g, o.dsig_q1inv, o.dsig_bq2, o.dsig_init, o.disig, o.dlse, nfold);
 }
 
-static inline void bsim_geometry(int B, int N, int M, int H, int Dx, int& HS, int& NTB, int& cpb, int& nblk) {
+static inline void bsim_geometry(int B, int N, int M, int H, int Dx, int& HS, int& NTB, int& cpb, int& nblk, int layers = 1) {
     // fewer than two waves per SIMD (1024 SIMDs) with one lane per (chain, m): spread a chain over 2M lanes.
     // Only for Dx <= 2: two waves per SIMD need <= 256 VGPRs, which the Dx >= 3 reverse kernel exceeds
     // (measured: 264-1056 B/lane of scratch when forced), and a spilling kernel is slower than a lone wave.
     const long long waves1 = ((long long)B * N * M + 63) / 64;
-    HS = (waves1 < 2048 && 2 * M <= 64 && (H / 2) % 4 == 0 && Dx <= 2) ? 2 : 1;
+    HS = (waves1 < 2048 && 2 * M <= 64 && (H / 2) % 4 == 0 && Dx <= 2 && (layers != 2 || g_tune_l2_split)) ? 2 : 1;
     NTB = ((N * M * HS + 63) / 64) * 64;
     if (NTB > 256) NTB = 256;
     cpb = NTB / (M * HS);
@@ -755,7 +756,7 @@ static int launch_bsim_bwd(const BsimBwdArgs& a, const BsimBwdOut& o, hipStream_
     using AC = BAcc<DX, DY>;
     constexpr int PS = BTileSlot<DX>::kFloats;
     int HS, NTB, cpb, nblk;
-    bsim_geometry(a.B, a.N, M, H, DX, HS, NTB, cpb, nblk);
+    bsim_geometry(a.B, a.N, M, H, DX, HS, NTB, cpb, nblk, PSVO_L);
     const int nwv = NTB / 64;
     // chunk of forward-tile entries reduced in registers per butterfly: 32 when a lane walks >= 32 entries
     const int walk = ((a.N + 3) / 4 + HS - 1) / HS;

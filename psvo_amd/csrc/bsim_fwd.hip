@@ -469,7 +469,7 @@ static int launch_bsim(const BsimArgs& a, hipStream_t stream) {
     constexpr int PS = TileSlot<DX>::kFloats;
     // fewer than two waves per SIMD (1024 SIMDs) with one lane per (chain, m): spread each chain over 2M lanes
     const long long waves1 = ((long long)a.B * a.N * M + 63) / 64;
-    const int HS = (waves1 < 2048 && 2 * M <= 64 && (H / 2) % 4 == 0) ? 2 : 1;
+    const int HS = (waves1 < 2048 && 2 * M <= 64 && (H / 2) % 4 == 0 && (PSVO_L == 1 || g_tune_l2_split)) ? 2 : 1;
     const int NP = ((a.N + 16 * HS - 1) / (16 * HS)) * (16 * HS);
     int NTB = ((a.N * M * HS + 63) / 64) * 64;
     if (NTB > 256) NTB = 256;

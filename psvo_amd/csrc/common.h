@@ -47,6 +47,32 @@ inline int launch_status() {
 // shorter struct leaves there) is refused loudly by every entry point instead of silently running the one-layer kernels
 inline bool desc_layers_ok(const psvo_desc* d) { return !d || (d->layers >= 0 && d->layers <= 2); }
 
+// PSVO_TUNE_L2_SPLIT (psvo_set_tuning): two-layer builds of the backward-simulation kernels -- 0 (default): one lane per
+// (chain, m) whatever the problem size, 1: spread a chain over 2 M lanes when that gives two waves per SIMD, as the one-layer
+// builds do.  (With the H x H layer on the matrix pipe a second wave per SIMD shares that pipe and the per-row overheads
+// double: measured)
+extern int g_tune_l2_split;
+
+// PSVO_TUNE_SKEW (psvo_set_tuning): phase offset between the workgroups that share a CU, in per cent of the kernel's own
+// estimate of its pair-phase length (0 = off = default).  See phase_skew().
+extern int g_tune_skew_pct;
+
+// Two workgroups that share a CU run the same program on the same amount of data, so they stay IN PHASE for the whole
+// launch: both are in their VALU-dense pair loop at the same time (each then runs at half rate -- the section timers of
+// bsim_bwd2 show the pair phase at 2 x its arithmetic floor) and both are in the latency-bound rest of the step at the same
+// time (vector ALU idle).  Delaying every other resident workgroup ONCE, at the start of the kernel, by about one pair-phase
+// length puts the two out of phase for good -- their step times are equal, so the offset persists -- and the pair loop of one
+// then runs under the latency of the other.  (MEASURED: no effect, C* and C5 alike -- both kernels are VALU-bound, and the
+// vector ALU does the same work whatever the phase; profiles/r03_bsim_bwd_C5_ab.md.  Kept as a knob.)  Which workgroup waits is read from the hardware: TG_ID of HW_REG_HW_ID is the
+// workgroup's slot on its CU (the same for all its waves), so the two residents of a CU always differ in it.
+__device__ __forceinline__ void phase_skew(int cycles) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (cycles > 0 && ((hw >> 16) & 1u)) {
+        for (int i = 0; i < cycles; i += 64 * 32) __builtin_amdgcn_s_sleep(32);      // (s_sleep n: 64 n cycles)
+    }
+}
+
 // an MLP argument carries the second hidden layer when this unit is compiled for two (NULL arguments pass: optional MLPs)
 inline bool mlp_layers_ok(const psvo_mlp* m) { return PSVO_L == 1 || !m || (m->Wh && m->bh); }
 
@@ -139,6 +165,22 @@ __device__ __forceinline__ T* arg_ptr(unsigned byte_off) {
     const kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
     typedef T* const __attribute__((address_space(4))) * pptr;
     return *(pptr)(kp + byte_off);
+}
+// NPTR (2, 4 or 8) pointer arguments that sit next to each other in the argument struct, fetched with ONE scalar load
+// (s_load_dwordx4 / x8 / x16).  A section that issues a dozen global loads through PSVO_ARG pays the scalar-cache latency of
+// each pointer in turn (s_load, s_waitcnt, global_load, s_load, ...: ~1500 cycles per step of bsim_bwd2 for loads that only
+// ISSUE); with the block form the wave waits once.  `byte_off` = offsetof(ArgsStruct, first field), a multiple of 8 NPTR.
+template <int NPTR>
+__device__ __forceinline__ void arg_block(unsigned byte_off, unsigned long long (&out)[NPTR]) {
+    static_assert(NPTR == 2 || NPTR == 4 || NPTR == 8, "pointer block of 2, 4 or 8");
+    asm volatile("" : "+s"(byte_off));
+    typedef const char __attribute__((address_space(4))) * kptr;
+    const kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef unsigned long long vec_t __attribute__((ext_vector_type(NPTR)));
+    typedef const vec_t __attribute__((address_space(4))) * vptr;
+    const vec_t v = *(vptr)(kp + byte_off);
+#pragma unroll
+    for (int i = 0; i < NPTR; ++i) out[i] = v[i];
 }
 #define PSVO_ARG(args_type, field) \
     ::psvo::arg_ptr<std::remove_pointer_t<decltype(args_type::field)>>((unsigned)offsetof(args_type, field))

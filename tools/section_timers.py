@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 AB = os.path.join(ROOT, "psvo_amd", "csrc", "ab")
-LIBT = os.path.join(AB, "libpsvo_hip_timers.so")
+LIBT = os.environ.get("PSVO_TIMERS_LIB") or os.path.join(AB, "libpsvo_hip_timers.so")     # (one unit of a family per library)
 
 
 def build(units):
