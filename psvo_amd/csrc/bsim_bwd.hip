@@ -88,6 +88,7 @@ extern "C" int psvo_bsim_backward(
     float* dGt, float* dmu1, float* dFm_part, float* dlogW_part, float* dbmu2_rows, float* dminit_rows,
     float* dimean_rows, float* sacc_part, void* stream) {
     using namespace psvo;
+    if (!desc_layers_ok(desc)) return PSVO_ERR_UNSUPPORTED;
     if (!desc || !Fm || !logW || !lse || !f || !g || !q1_inv || !sig_f || !sig_g || !sig_q1inv || !sig_bq2 || !bmu2 ||
         !minit || !sig_init || !imean || !isig || !obs || !eps_b || !bwX || !sel || !lam2_all || !om_all ||
         !mu1_all || !dscore || !xt || !dFt || !dGt || !dmu1 || !dFm_part || !dlogW_part || !dbmu2_rows ||

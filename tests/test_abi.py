@@ -67,8 +67,9 @@ def test_invalid_arguments_are_rejected_without_a_device(built_lib):
         for name in ("psvo_filter_backward", "psvo_bsim_forward", "psvo_bsim_backward", "psvo_bsimwr_forward",
                      "psvo_bsimwr_backward"):
             fn = getattr(lib, name)
-            args = [ctypes.byref(d)] + [None] * (len(_lib.SIGNATURES[name][1]) - 1)
-            assert fn(*args) in (_lib.PSVO_ERR_UNSUPPORTED, _lib.PSVO_ERR_INVALID), name
+            null = lambda ty: 0 if ty in (ctypes.c_int, ctypes.c_longlong) else 0.0 if ty in (ctypes.c_float, ctypes.c_double) else None
+            args = [ctypes.byref(d)] + [null(ty) for ty in _lib.SIGNATURES[name][1][1:]]
+            assert fn(*args) == _lib.PSVO_ERR_UNSUPPORTED, name
     d.layers = 1
     with pytest.raises(ValueError):
         _lib.check(_lib.PSVO_ERR_UNSUPPORTED, "x")
