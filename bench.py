@@ -495,15 +495,15 @@ def main():
         value = world * units * args.steps / elapsed
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # figure is the committed, calibrated FETCH_SIZE / WRITE_SIZE measurement of the same workload
-        # (tools/traffic_probe.py + tools/traffic_report.py -> profiles/r01_hbm_traffic_Cstar.json), else null
+        # (tools/profile_round.sh: traffic_probe.py + traffic_report.py -> profiles/r03_hbm_traffic_Cstar.json), else null
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r02_hbm_traffic_Cstar.json")
+        tp = os.path.join(ROOT, "profiles", "r03_hbm_traffic_Cstar.json")
         if args.workload == "C*" and os.path.exists(tp):
             key = {"psvo_bsim_backward": "bsim_bwd", "psvo_bsim_forward": "bsim_fwd_kernel",
                    "psvo_filter_backward": "filter_bwd_kernel", "psvo_filter_forward": "filter_fwd"}[dominant]
             for k, v in json.load(open(tp))["kernels"].items():
                 if key in k and "finalize" not in k and v["hbm_MB_per_launch"] * 1e6 > (traffic or 0.0):
-                    traffic, traffic_src = v["hbm_MB_per_launch"] * 1e6, "profiles/r02_hbm_traffic_Cstar.json"
+                    traffic, traffic_src = v["hbm_MB_per_launch"] * 1e6, "profiles/r03_hbm_traffic_Cstar.json"
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

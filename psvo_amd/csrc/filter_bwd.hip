@@ -499,8 +499,10 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
     load_step(T - 1, c_anc, c_x, c_e, c_m2, c_y, c_mean1, c_fmean, c_dfm, c_sc);
     __syncthreads();
 
+    SEC_INIT(filter_bwd)
     // t = 0 (own step constants, block sums instead of the scatter) is peeled out of the loop: see filter_fwd_lpp_kernel
     auto step = [&](auto first_tag, const int t) {
+        SEC(0);   // (lpp) loop overhead
         const size_t tb = (size_t)t * B + b;
         constexpr bool first = decltype(first_tag)::value;
         const BStepK<DX> K = first ? K0 : K1;
@@ -519,6 +521,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
             load_step(t - 1, n_anc, n_x, n_e, n_m2, n_y, n_mean1, n_fmean, n_dfm, n_sc);
             anc_next = load_anc(t - 2);
         }
+        SEC(1);   // (lpp) issue of the prefetch loads
         float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX];
         const int anc = c_anc;
 #pragma unroll
@@ -547,6 +550,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
         dlnw = first ? 0.f : dlw;
         const float cnt = (p == 0) ? 1.f : 0.f;     // sums over particles take the quad's first lane
 
+        SEC(2);   // (lpp) proposal mean, d logW
         // ---- emission: hidden units of MLP_g split over the quad ----------------------------------------------------
         float dxp[DX];                              // this lane's PARTIAL of d x (summed over the quad below)
 #pragma unroll
@@ -566,6 +570,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
             }
             MG::template bwd_input_part<P>(wg, p, x, dgm, dxp);
         }
+        SEC(3);   // (lpp) MLP_g forward, quad sum, input gradient, dG row store
         // ---- transition and proposal densities ------------------------------------------------------------------------
         float dfmean[DX];
 #pragma unroll
@@ -610,8 +615,10 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
                 for (int d = 0; d < DX; ++d) a.dF[(tb * DX + d) * N + n] = dFn[d];
             }
         }
+        SEC(4);   // (lpp) densities, scatter targets from LDS, dP / dF row stores
         MQ::template bwd_input_part<P>(wq1, p, x, dPn, dxp);
         if (!a.bootstrap) MQ::template bwd_input_part<P>(wfm, p, x, dFn, dxp);
+        SEC(5);   // (lpp) MLP_q1 (/ MLP_f) input gradient
 
         // ---- x = mu + c eps, mu = c (mean1/s1 + mu2/s2) -------------------------------------------------------------------
         float dmean1[DX];
@@ -630,6 +637,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
                 dmean1[d] = dmu;
             }
         }
+        SEC(6);   // (lpp) quad sums of d x, product-of-Gaussians gradient, d mu2 row store
         // ---- gather backward: scatter-add into the parents (SVO.py:255-257), one dimension per lane of the quad --------
         if (!first) {
             if (valid) {
@@ -657,6 +665,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
                 }
             }
         }
+        SEC(7);   // (lpp) LDS scatter-add into the parents
         if (t >= 1) {
             c_anc = n_anc;
 #pragma unroll
@@ -675,6 +684,7 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
             acc[AC::kSet + i] += (!first && p == 0) ? inc[i] : 0.f;
         }
         __syncthreads();
+        SEC(8);   // (lpp) register rotation (waits for the prefetch) + barrier
     };
     for (int t = T - 1; t >= 1; --t) step(std::false_type{}, t);
     step(std::true_type{}, 0);

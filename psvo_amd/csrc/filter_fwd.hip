@@ -388,14 +388,14 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
     // t = 0 (its own proposal constants) is peeled: the loop proper then carries one set of step constants
     // instead of selecting between two every step (scalar-register pressure: spills cost v_readlane + s_nop)
     auto step = [&](auto first_tag, const int t) {
-        SEC(0);
+        SEC(0);   // (lpp) loop overhead
         const size_t tb = (size_t)t * B + b;
         const StepK<DX> K = decltype(first_tag)::value ? K0 : K1;
         float eps_n[DX], mu2_n[DX], obs_n[DY], u_n = 0.f;
         int idx_n = 0;
         if (t + 1 < T) load_inputs(t + 1, eps_n, mu2_n, obs_n, u_n, idx_n);
 
-        SEC(1);
+        SEC(1);   // (lpp) issue of the prefetch loads
         // ---- proposal (SVO.py:186-197), densities: the same in the four lanes of the particle --------
         float mu[DX], x[DX];
 #pragma unroll
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         const float q_lp = diag_lp<DX>(x, mu, K.ic, K.lq);
         const float f_lp = diag_lp<DX>(x, fmean, K.ifs, K.lf);
 
-        SEC(2);
+        SEC(2);   // (lpp) proposal, q / f densities
         // ---- the MLPs of the step, hidden units split over the quad ------------------------------------
         // (the lane's weight slice is loop-invariant: the compiler keeps it in VGPRs when the budget allows;
         //  otherwise an opaque LDS offset per step makes it re-read the slice instead of spilling it)
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
             }
         }
 
-        SEC(3);   // MLPs, quad sums, weight, history stores
+        SEC(3);   // (lpp) MLPs, quad sums, weight, history stores
         // ---- log-sum-exp over particles + CDF: per-wave maxima, one barrier ------------------------------
         const float wmx = wave_max(lw);
         const float wbase = (wmx == ninf) ? 0.f : wmx;
@@ -467,9 +467,9 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
                 for (int d = 0; d < DX; ++d) sf[d * NPT + pn] = fm[d];
             }
         }
-        SEC(4);   // wave max / scan, staging writes
+        SEC(4);   // (lpp) wave max / scan, staging writes
         __syncthreads();
-        SEC(5);   // barrier
+        SEC(5);   // (lpp) barrier
         // combine the (max, sum) pairs of the <= 16 waves in the lanes of a row: lane i holds wave i
         const int li = lane & 15;
         const float m_i = li < nw ? red[li] : ninf;
@@ -484,14 +484,14 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
         const float lse_t = fmaf(kLn2, log2_fast(total), gmx);
         if (tid == 3) a.lse[tb] = lse_t;
 
-        SEC(6);   // cross-wave combination
+        SEC(6);   // (lpp) cross-wave combination
         if (a.resample) {
             if (p == 0) {
                 cdf[pn] = sc;
                 if ((pn & 15) == 15) piv[pn >> 4] = sc;
             }
             __syncthreads();
-            SEC(7);   // cdf store + barrier
+            SEC(7);   // (lpp) cdf store + barrier
             int idx;
             if (a.idx_in) {
                 idx = idx_c;
@@ -523,9 +523,9 @@ __global__ void __launch_bounds__(MAXT) filter_fwd_lpp_kernel(const FilterArgs a
                 }
             }
             lnw = neg_logN;
-            SEC(8);   // search, gather, stores
+            SEC(8);   // (lpp) search, gather, stores
             __syncthreads();  // staged arrays / red[] are rewritten next step
-            SEC(9);   // barrier
+            SEC(9);   // (lpp) barrier
         } else {
 #pragma unroll
             for (int d = 0; d < DX; ++d) {

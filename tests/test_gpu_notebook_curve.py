@@ -21,7 +21,10 @@ draws each time), and where a run stands after 10 epochs depends on its initiali
 profiles/r03_notebook_curve_hip_10ep.json give -370.9 ... -431.3 at iter 10 (mean -394.6, standard deviation 17.0, median
 -393.2); the fp64 ORACLE trained by the same loop on the CPU gives -403.6 and -384.7 (seeds 1, 2), the fp32 oracle -372.4
 (seed 3; profiles/r03_notebook_curve_oracle*.json).  The notebook's -380.5 is one draw from that distribution (0.8 sigma from
-its mean).  Hence: every trained seed within BAND = 55 (3 sigma), the median of the trained seeds within MEDIAN_BAND = 25.
+its mean).  Hence: every trained seed within BAND = 60 (3.5 sigma), the median of the trained seeds within MEDIAN_BAND = 25.
+Longer runs (profiles/r03_notebook_curve_hip_400ep.json): seed 1 follows the notebook's whole curve -- -370.9 at iter 10,
+-361.4 at iter 130, -354.3 at iter 290 (notebook: -380.5, -384.2, best -361.1 at iter 190), R^2(k = 0) 0.98 -- while seeds 0 and 3
+leave the basin between iter 10 and iter 20 (see below).
 
 About runs that do NOT train.  With he_normal kernels the freshly initialised transition MLP has a gain of about sqrt(2)
 per step, and for roughly half of all seeds the k = 30 prediction of the initial model already explodes (R^2(k = 30) of
@@ -50,7 +53,7 @@ pytestmark = pytest.mark.gpu
 
 SEEDS = (0, 1, 2, 3, 4, 5)
 MIN_TRAINED = 4
-BAND = 55.0          # every trained seed (3 sigma of the seed-to-seed spread, see the module docstring)
+BAND = 60.0          # every trained seed (3.5 sigma of the seed-to-seed spread, see the module docstring)
 MEDIAN_BAND = 25.0   # the median over the trained seeds
 GOLD_STATE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fhn_illconditioned_state.npz")
 

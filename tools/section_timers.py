@@ -37,6 +37,21 @@ def build(units):
     print(LIBT)
 
 
+def legend(unit, lpp):
+    """labels of the SEC(i) marks of a timer family, read from the source: `SEC(i);   // text`; the four-lanes-per-particle
+    filter kernels mark theirs "(lpp)" (the same timer array serves both kernel shapes, one runs per workload)"""
+    import re
+    src = {"bsim_bwd2": "bsim_bwd2_impl.h", "bsim_bwd": "bsim_bwd_impl.h"}.get(unit, unit + ".hip")
+    out = {}
+    for m in re.finditer(r"SEC\((\d+)\);\s*//\s*(.*)", open(os.path.join(ROOT, "psvo_amd", "csrc", src)).read()):
+        text = m.group(2).strip()
+        is_lpp = text.startswith("(lpp)")
+        if unit.startswith("filter") and is_lpp != lpp:
+            continue
+        out.setdefault(int(m.group(1)), text.replace("(lpp) ", ""))
+    return out
+
+
 def run(workload, units, steps=5):
     os.environ["PSVO_HIP_LIB"] = LIBT
     import torch
@@ -44,7 +59,7 @@ def run(workload, units, steps=5):
     from psvo_amd import _lib
     from psvo_amd.optim import FlatParams
     wl = bench.WORKLOADS[workload]
-    obj, B, T, N, Dx, Dy, M, H, Dh = wl
+    obj, B, T, N, Dx, Dy, M, H, Dh = wl[:9]
     FLAGS, model, smc = bench.build_objective(wl, "cuda")
     flat = FlatParams(model)
     smc.generator = torch.Generator(device="cuda").manual_seed(0)
@@ -71,9 +86,11 @@ def run(workload, units, steps=5):
         fns[unit](buf, 0)
         tot = sum(buf)
         print("%s @ %s: cycles of lane 0 / workgroup (0,0), %d launches, T = %d" % (unit, workload, steps, T))
+        names = legend(unit, lpp=(N <= 128))
         for i, v in enumerate(buf):
             if v:
-                print("  SEC(%2d) %12d  %8.0f cycles/time-step  %5.1f %%" % (i, v, v / steps / T, 100.0 * v / tot))
+                print("  SEC(%2d) %12d  %8.0f cycles/time-step  %5.1f %%   %s"
+                      % (i, v, v / steps / T, 100.0 * v / tot, names.get(i, "")))
         print("  total   %12d  %8.0f cycles/time-step" % (tot, tot / steps / T))
 
 
