@@ -413,15 +413,22 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
     float* wq1 = smem;
     float* wf = wq1 + MQ::kSize;
     float* wg = wf + MQ::kSize;
-    float* accP = wg + MG::kSize;        // [2][DX][NPT] scatter targets d P1 (+ d Fm when bootstrap)
-    float* accF = accP + 2 * DX * NPT;   // [2][DX][NPT] d Fm (only when !bootstrap)
-    float* red = accF + 2 * DX * NPT;    // 16 floats
+    // Scatter targets of the resampling gather's reverse (children add into their parent): ONE COPY PER WAVE.  Float atomics
+    // from several waves on one LDS word are applied in arrival order, so the sums -- and with them every gradient of the
+    // step -- differed in the last bits from run to run (round-2 review).  Within a wave the atomics of one instruction are
+    // resolved in lane order and instructions in program order; with a copy per wave and the parent adding the copies in
+    // wave order, the order of every sum is fixed.  Cost: nw reads + clears per value where there was one (~1 % of the
+    // kernel); LDS 2 x nw x DX x NPT floats (16 KB at Dx = 2, N = 128).
+    const int CP = DX * NPT;              // floats of one copy
+    float* accP = wg + MG::kSize;         // [2][nw][DX][NPT] d P1 (+ d Fm when bootstrap)
+    float* accF = accP + 2 * nw * CP;     // [2][nw][DX][NPT] d Fm (only when !bootstrap)
+    float* red = accF + 2 * nw * CP;      // 16 floats
 
     MQ::load(wq1, a.q1, tid, NT);
     if (!a.bootstrap) MQ::load(wf, a.f, tid, NT);
     MG::load(wg, a.g, tid, NT);
     const float* wfm = a.bootstrap ? wq1 : wf;
-    for (int i = tid; i < 4 * DX * NPT; i += NT) accP[i] = 0.f;
+    for (int i = tid; i < 4 * nw * CP; i += NT) accP[i] = 0.f;
 
     float sq1[DX], sq2[DX], sfv[DX], s0[DX], fs0[DX], isg[DY];
 #pragma unroll
@@ -509,10 +516,10 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
         float inc[AC::kSet];
 #pragma unroll
         for (int i = 0; i < AC::kSet; ++i) inc[i] = 0.f;
-        float* curP = accP + (t & 1) * DX * NPT;
-        float* nxtP = accP + ((t + 1) & 1) * DX * NPT;
-        float* curF = accF + (t & 1) * DX * NPT;
-        float* nxtF = accF + ((t + 1) & 1) * DX * NPT;
+        float* curP = accP + (t & 1) * nw * CP;                      // all waves' copies of this step's targets
+        float* nxtP = accP + ((t + 1) & 1) * nw * CP + wave * CP;    // this wave's copy for step t - 1
+        float* curF = accF + (t & 1) * nw * CP;
+        float* nxtF = accF + ((t + 1) & 1) * nw * CP + wave * CP;
 
         float n_x[DX], n_e[DX], n_m2[DX], n_y[DY], n_mean1[DX], n_fmean[DX], n_dfm[DX], n_sc[4];
         int n_anc = n;
@@ -522,6 +529,39 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
             anc_next = load_anc(t - 2);
         }
         SEC(1);   // (lpp) issue of the prefetch loads
+        // the scatter targets of this step (complete since the barrier that ended step t + 1) are requested HERE, a whole
+        // MLP pass ahead of their use, so that the nw reads per value cost issue slots only
+        float sp[DX], sf[DX];
+        {
+            float cp[8][DX];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                // (unconditional reads of a clamped copy + select: a guarded load is a branch, and a wait, per copy)
+                const int wc = w < nw ? w : nw - 1;
+#pragma unroll
+                for (int d = 0; d < DX; ++d) cp[w][d] = curP[wc * CP + d * NPT + pn];
+            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                sp[d] = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sp[d] += (w < nw) ? cp[w][d] : 0.f;        // the waves' copies, in wave order
+                sf[d] = 0.f;
+            }
+        }
+        if (!a.bootstrap) {
+            float cf[8][DX];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int wc = w < nw ? w : nw - 1;
+#pragma unroll
+                for (int d = 0; d < DX; ++d) cf[w][d] = curF[wc * CP + d * NPT + pn];
+            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sf[d] += (w < nw) ? cf[w][d] : 0.f;
+        }
         float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX];
         const int anc = c_anc;
 #pragma unroll
@@ -586,24 +626,26 @@ __global__ void __launch_bounds__(512) filter_bwd_lpp_kernel(const FilterBwdArgs
         float dPn[DX], dFn[DX];
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            dPn[d] = curP[d * NPT + pn];
+            dPn[d] = sp[d];
             const float ext = c_dfm[d];
             if (a.bootstrap) {
                 dPn[d] += ext;
                 dFn[d] = 0.f;
             } else {
-                dFn[d] = curF[d * NPT + pn] + ext;
+                dFn[d] = sf[d] + ext;
             }
             if (!valid) {
                 dPn[d] = 0.f;
                 dFn[d] = 0.f;
             }
         }
-        if (p == 0) {   // (only this quad reads these entries, in the wave instruction above: clear them for step t-2)
+        // (only this quad reads these entries, in the wave instructions above: clear them for step t-2; lane p takes the
+        //  copies w = p, p + 4)
+        for (int w = p; w < nw; w += 4) {
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
-                curP[d * NPT + pn] = 0.f;
-                if (!a.bootstrap) curF[d * NPT + pn] = 0.f;
+                curP[w * CP + d * NPT + pn] = 0.f;
+                if (!a.bootstrap) curF[w * CP + d * NPT + pn] = 0.f;
             }
         }
         if (valid) {
@@ -773,7 +815,7 @@ static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipS
     if constexpr (kLppOk) {
         if (a.N <= 128) {   // latency-bound regime: four lanes per particle
             const int NT4 = (4 * a.N + 63) & ~63;
-            const size_t lds4 = sizeof(float) * (2 * MQ::kSize + MG::kSize + 4 * DX * (NT4 / 4) + 16);
+            const size_t lds4 = sizeof(float) * (2 * MQ::kSize + MG::kSize + 4 * (NT4 / 64) * DX * (NT4 / 4) + 16);
             hipLaunchKernelGGL((filter_bwd_lpp_kernel<DX, DY, H>), dim3(a.B), dim3(NT4), lds4, stream, a);
             lpp = true;
         }

@@ -101,3 +101,40 @@ def test_local_step_captures_without_flat_parameters():
     spec.loader.exec_module(probe)
     bad = probe.run_all(["aesmc+noflat", "psvo+overlap+noflat", "psvo+padded+overlap+flat", "psvowr+overlap+noflat"])
     assert not bad, bad
+
+
+def test_training_step_gradients_are_bit_reproducible(built_lib):
+    """No float atomics across waves are left on the N <= 128 path (round 3: the resampling gather's reverse pass scatters
+    into one LDS copy per wave and the parent adds the copies in wave order), so the gradient of one training step is the same
+    bit pattern from run to run, issued eagerly or replayed from the captured hipGraph."""
+    import torch
+    from tests import helpers as Hh
+    from tests import test_gpu_parity as TP
+    from psvo_amd import autograd
+    from psvo_amd.graph import GraphedStep
+    from psvo_amd.optim import FlatParams
+    # 3 sequences x 128 particles: eight waves per sequence in the filter kernels, children of one parent spread over waves
+    FLAGS, model, smc, obs, noise = TP._setup("PSVO", 3, 12, 128, 8, 2, 1, 32, True, True, seed=11)
+    nz = Hh.noise_to_hip(noise, "cuda")
+    flat = FlatParams(model)
+    obs_c = obs.float().cuda()
+
+    def local():
+        flat.zero_grad()
+        z, _ = smc.get_log_ZSMC(obs_c, None, noise=nz)
+        with autograd.deferred_join():
+            z.backward()
+        return z.detach()
+    grads = []
+    for _ in range(4):
+        z = local()
+        torch.cuda.synchronize()
+        grads.append((flat.grad.clone(), z.clone()))
+    for g, z in grads[1:]:
+        assert torch.equal(g, grads[0][0]) and torch.equal(z, grads[0][1])
+    step = GraphedStep(local)
+    for _ in range(3):
+        z = step()
+        torch.cuda.synchronize()
+        assert torch.equal(flat.grad, grads[0][0]) and torch.equal(z, grads[0][1])
+    assert float(grads[0][0].abs().max()) > 0
