@@ -35,6 +35,7 @@ struct FilterBwdArgs {
     float *dP, *dF, *dG, *dmu2, *dm0, *dfm0;
     float* sacc;             // (B, NACC) per-sequence scalar accumulators (see finalize)
     float* dm2_rows;         // (T,B,Dx,N) per-particle d mu2 rows, summed over N by row_sum_kernel afterwards
+    int wave_copies;         // filter_bwd_kernel: one scatter-target copy per wave (set by the launcher when LDS has room)
 };
 
 template <int DX, int DY>
@@ -105,15 +106,19 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
     float* wq1 = smem;
     float* wf = wq1 + MQ::kSize;
     float* wg = wf + MQ::kSize;
-    float* accP = wg + MG::kSize;        // [2][DX][NT] scatter targets d P1 (+ d Fm when bootstrap)
-    float* accF = accP + 2 * DX * NT;    // [2][DX][NT] d Fm (only when !bootstrap)
-    float* red = accF + 2 * DX * NT;     // 16 floats
+    // scatter targets: one copy per wave when the launcher found room for them (a.wave_copies; see filter_bwd_lpp_kernel) --
+    // fixed summation order --, else one shared copy and float atomics across the waves
+    const int nc = a.wave_copies ? nw : 1;
+    const int CP = DX * NT;               // floats of one copy
+    float* accP = wg + MG::kSize;         // [2][nc][DX][NT] scatter targets d P1 (+ d Fm when bootstrap)
+    float* accF = accP + 2 * nc * CP;     // [2][nc][DX][NT] d Fm (allocated only when !bootstrap)
+    float* red = accF + (a.bootstrap ? 0 : 2 * nc * CP);      // 16 floats
 
     MQ::load(wq1, a.q1, tid, NT);
     if (!a.bootstrap) MQ::load(wf, a.f, tid, NT);
     MG::load(wg, a.g, tid, NT);
     const float* wfm = a.bootstrap ? wq1 : wf;
-    for (int i = tid; i < 4 * DX * NT; i += NT) accP[i] = 0.f;
+    for (int i = tid; i < (a.bootstrap ? 2 : 4) * nc * CP; i += NT) accP[i] = 0.f;
 
     float sq1[DX], sq2[DX], sfv[DX], s0[DX], fs0[DX], isg[DY];
 #pragma unroll
@@ -206,10 +211,11 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
         float inc[AC::kSet];  // this step's contribution to the per-dimension sums (set chosen below)
 #pragma unroll
         for (int i = 0; i < AC::kSet; ++i) inc[i] = 0.f;
-        float* curP = accP + (t & 1) * DX * NT;
-        float* nxtP = accP + ((t + 1) & 1) * DX * NT;
-        float* curF = accF + (t & 1) * DX * NT;
-        float* nxtF = accF + ((t + 1) & 1) * DX * NT;
+        const int mine = a.wave_copies ? wave * CP : 0;
+        float* curP = accP + (t & 1) * nc * CP;                     // all copies of this step's targets
+        float* nxtP = accP + ((t + 1) & 1) * nc * CP + mine;        // this wave's copy (or the shared one) for step t - 1
+        float* curF = accF + (t & 1) * nc * CP;
+        float* nxtF = accF + ((t + 1) & 1) * nc * CP + mine;
 
         // ---- forward quantities of this step (prefetched) ----------------------------------------------
         float n_x[DX], n_e[DX], n_m2[DX], n_y[DY], n_mean1[DX], n_fmean[DX], n_dfm[DX], n_sc[4];
@@ -220,6 +226,43 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
             anc_next = load_anc(t - 2);
         }
         SEC(1);   // issue of the prefetch loads
+        // this step's scatter targets (complete since the barrier that ended step t + 1): requested here, ahead of their use
+        float sp[DX], sf[DX];
+        if (nc == 1) {           // (one shared copy, float atomics: N > 256)
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                sp[d] = curP[d * NT + tid];
+                sf[d] = a.bootstrap ? 0.f : curF[d * NT + tid];
+            }
+        } else {
+            float cp[8][DX];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int wc = w < nc ? w : nc - 1;       // (unconditional reads of a clamped copy + select)
+#pragma unroll
+                for (int d = 0; d < DX; ++d) cp[w][d] = curP[wc * CP + d * NT + tid];
+            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                sp[d] = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sp[d] += (w < nc) ? cp[w][d] : 0.f;       // in wave order
+                sf[d] = 0.f;
+            }
+        }
+        if (nc > 1 && !a.bootstrap) {
+            float cf[8][DX];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int wc = w < nc ? w : nc - 1;
+#pragma unroll
+                for (int d = 0; d < DX; ++d) cf[w][d] = curF[wc * CP + d * NT + tid];
+            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sf[d] += (w < nc) ? cf[w][d] : 0.f;
+        }
         float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX];
         const int anc = c_anc;
 #pragma unroll
@@ -283,15 +326,15 @@ __global__ void __launch_bounds__(MAXT) filter_bwd_kernel(const FilterBwdArgs a)
         float dPn[DX], dFn[DX];
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
-            dPn[d] = curP[d * NT + tid];
-            curP[d * NT + tid] = 0.f;
+            dPn[d] = sp[d];
+            for (int w = 0; w < nc; ++w) curP[w * CP + d * NT + tid] = 0.f;
             const float ext = c_dfm[d];
             if (a.bootstrap) {
                 dPn[d] += ext;
                 dFn[d] = 0.f;
             } else {
-                dFn[d] = curF[d * NT + tid] + ext;
-                curF[d * NT + tid] = 0.f;
+                dFn[d] = sf[d] + ext;
+                for (int w = 0; w < nc; ++w) curF[w * CP + d * NT + tid] = 0.f;
             }
             if (!valid) {
                 dPn[d] = 0.f;
@@ -808,7 +851,13 @@ static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipS
     using MQ = MlpLds<DX, H, DX, PSVO_L>;
     using MG = MlpLds<DX, H, DY, PSVO_L>;
     const int NT = (a.N + 63) & ~63;
-    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 4 * DX * NT + 16);
+    FilterBwdArgs aw = a;
+    const size_t arrays = a.bootstrap ? 2 : 4;       // d P1 (+ d Fm) double-buffered; the d Fm pair only without bootstrap
+    size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + arrays * (size_t)(NT / 64) * DX * NT + 16);
+    // (N <= 256 only: at N = 512 the eight copies cost 3 % of the C5 step -- 32 reads and clears per particle and step at
+    //  Dx = 4 -- and C5 is the configuration that can least afford it; there the scatter keeps its float atomics)
+    aw.wave_copies = a.N <= 256 && lds <= 150 * 1024;
+    if (!aw.wave_copies) lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + arrays * DX * NT + 16);
     clear_hip_error();
     constexpr bool kLppOk = (H % 16 == 0) && (PSVO_L == 2 || (H <= 32 && DX <= 3));   // (two layers: as in filter_fwd.hip)
     bool lpp = false;
@@ -822,9 +871,9 @@ static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipS
     }
     if (lpp) {
     } else if (NT <= 256)
-        hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, a);
+        hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, aw);
     else
-        hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT), lds, stream, a);
+        hipLaunchKernelGGL((filter_bwd_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT), lds, stream, aw);
     if (a.two_q) {
         const long long rows = (long long)a.T * a.B * DX;
         hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a.dm2_rows, rows,
@@ -897,6 +946,7 @@ PSVO_ENTRY(psvo_filter_backward)(
     if (desc->N > 512) return PSVO_ERR_UNSUPPORTED;
 
     FilterBwdArgs a;
+    a.wave_copies = 0;
     a.B = desc->B; a.T = desc->T; a.N = desc->N;
     a.resample = desc->resample; a.two_q = desc->two_q; a.bootstrap = desc->bootstrap; a.emission = desc->emission;
     a.q1 = *q1; a.f = desc->bootstrap ? *q1 : *f; a.g = *g;

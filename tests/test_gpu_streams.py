@@ -104,17 +104,25 @@ def test_local_step_captures_without_flat_parameters():
 
 
 def test_training_step_gradients_are_bit_reproducible(built_lib):
-    """No float atomics across waves are left on the N <= 128 path (round 3: the resampling gather's reverse pass scatters
+    """No float atomics across waves are left on the N <= 256 path (round 3: the resampling gather's reverse pass scatters
     into one LDS copy per wave and the parent adds the copies in wave order), so the gradient of one training step is the same
     bit pattern from run to run, issued eagerly or replayed from the captured hipGraph."""
+    from tests import test_gpu_parity as TP
+    # 3 sequences x 128 particles: eight waves per sequence in the filter kernels, children of one parent spread over waves
+    _reproducible(TP._setup("PSVO", 3, 12, 128, 8, 2, 1, 32, True, True, seed=11))
+    # ... and N = 200 / 256: one lane per particle, four waves per sequence (one scatter copy per wave as well; above 256 the
+    # reverse filter keeps its float atomics: the copies cost 3 % of the C5 step)
+    _reproducible(TP._setup("PSVO", 2, 8, 200, 4, 2, 1, 32, True, True, seed=12))
+    _reproducible(TP._setup("AESMC", 2, 8, 256, 1, 4, 1, 32, False, True, seed=13))
+
+
+def _reproducible(setup):
     import torch
     from tests import helpers as Hh
-    from tests import test_gpu_parity as TP
     from psvo_amd import autograd
     from psvo_amd.graph import GraphedStep
     from psvo_amd.optim import FlatParams
-    # 3 sequences x 128 particles: eight waves per sequence in the filter kernels, children of one parent spread over waves
-    FLAGS, model, smc, obs, noise = TP._setup("PSVO", 3, 12, 128, 8, 2, 1, 32, True, True, seed=11)
+    FLAGS, model, smc, obs, noise = setup
     nz = Hh.noise_to_hip(noise, "cuda")
     flat = FlatParams(model)
     obs_c = obs.float().cuda()
