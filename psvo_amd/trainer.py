@@ -196,15 +196,40 @@ class trainer:
         return metrics, log
 
     def _save_epoch_samples(self, epoch, obs_test, hidden_test, write):
-        """trajectory_<epoch>.p / y_hat_<epoch>.p for the first saving_num held-out sequences (trainer.py:170-186)"""
+        """trajectory_<epoch>.p / y_hat_<epoch>.p for the first saving_num held-out sequences (trainer.py:170-186) and, for
+        two-dimensional latents, lattice_val_<epoch>.p -- the data behind the reference's quiver plot (trainer.py:337-361),
+        which its notebook reads back (notebooks/PSVO.ipynb: `lattice_dict["X_trajs"], ["X"], ["nextX"]`)."""
         self.saving_feed_dict = {self.obs: obs_test[:self.saving_num], self.hidden: hidden_test[:self.saving_num]}
+        Xs_val = None
         for flag, fetch, stem in ((self.save_trajectory, "Xs", "trajectory"), (self.save_y_hat, "y_hat", "y_hat")):
             if not flag:
                 continue
             val = self.evaluate(fetch, self.saving_feed_dict, average=False)      # (collective: every rank takes part)
+            if fetch == "Xs":
+                Xs_val = val
             if write:
                 with open(self.epoch_data_DIR + "{}_{}.p".format(stem, epoch), "wb") as f:
                     pickle.dump({fetch: val}, f)
+        if self.Dx == 2 and Xs_val is not None:      # (the reference draws from the trajectories it has just saved)
+            lattice = self.quiver_lattice(Xs_val)
+            if write:
+                with open(self.epoch_data_DIR + "lattice_val_{}.p".format(epoch), "wb") as f:
+                    pickle.dump(lattice, f)
+
+    def quiver_lattice(self, Xs_val, shape=(25, 25), margin=0.05):
+        """{"X_trajs", "X", "nextX"} of trainer.draw_2D_quiver_plot (trainer.py:337-361) without the figure: the particle-mean
+        trajectories (saving_num, T, 2), a 25 x 25 lattice over their bounding box and f.mean on it (SMC.get_nextX).  The
+        reference takes the box from the axes of its plot of those trajectories, i.e. the data range widened by matplotlib's
+        default 5 % margin on either side; that is restated here."""
+        X_trajs = np.mean(np.asarray(Xs_val), axis=2)[:self.saving_num]
+        lo, hi = X_trajs.reshape(-1, 2).min(axis=0), X_trajs.reshape(-1, 2).max(axis=0)
+        pad = margin * (hi - lo)
+        x1 = np.linspace(lo[0] - pad[0], hi[0] + pad[0], num=shape[0])
+        x2 = np.linspace(lo[1] - pad[1], hi[1] + pad[1], num=shape[1])
+        X = np.stack(np.meshgrid(x1, x2), axis=-1)                         # (25, 25, 2), trainer.define2Dlattice
+        with torch.no_grad():
+            nextX = self.SMC.get_nextX(self._to_dev(X.reshape(-1, 2))).reshape(shape[1], shape[0], 2).cpu().numpy()
+        return {"X_trajs": X_trajs, "X": X, "nextX": nextX}
 
     def close_session(self):
         pass

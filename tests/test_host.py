@@ -323,3 +323,26 @@ def test_runner_objective_switch():
     FLAGS.AESMC = FLAGS.IWAE = True
     with pytest.raises(AssertionError):
         runner._objective(SSM(FLAGS), FLAGS)
+
+
+def test_quiver_lattice_dictionary():
+    """lattice_val_<epoch>.p (trainer.py:337-361): keys and shapes the reference's notebook reads back; the lattice spans
+    the particle-mean trajectories' bounding box widened by 5 % and nextX = f.mean on it (oracle's get_nextX)"""
+    from psvo_amd.trainer import trainer
+    from psvo_amd.SMC.SVO import SVO
+    torch.manual_seed(5)
+    FLAGS = Hh.make_flags("SVO", n_particles=4)
+    m = Hh.perturb_(SSM(FLAGS))
+    tr = trainer(m, SVO(m, FLAGS), FLAGS)
+    tr.saving_num = 3
+    Xs = np.random.RandomState(0).randn(5, 7, 4, 2)
+    d = tr.quiver_lattice(Xs)
+    assert set(d) == {"X_trajs", "X", "nextX"}
+    assert d["X_trajs"].shape == (3, 7, 2) and d["X"].shape == (25, 25, 2) and d["nextX"].shape == (25, 25, 2)
+    assert np.allclose(d["X_trajs"], Xs[:3].mean(axis=2))
+    lo, hi = d["X_trajs"].reshape(-1, 2).min(0), d["X_trajs"].reshape(-1, 2).max(0)
+    assert np.allclose(d["X"][0, 0], lo - 0.05 * (hi - lo)) and np.allclose(d["X"][-1, -1], hi + 0.05 * (hi - lo))
+    assert np.allclose(d["X"][0, :, 1], d["X"][0, 0, 1]) and np.allclose(d["X"][:, 0, 0], d["X"][0, 0, 0])  # meshgrid "xy"
+    o = O.OracleSVO(m.export_reference_layout(torch.float64), Hh.oracle_flags(FLAGS, "SVO"))
+    ref = o.get_nextX(torch.as_tensor(d["X"].reshape(-1, 2))).reshape(25, 25, 2).numpy()
+    assert np.allclose(d["nextX"], ref, atol=1e-5)
