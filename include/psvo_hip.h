@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PSVO_ABI_VERSION 5
+#define PSVO_ABI_VERSION 6
 
 typedef enum {
     PSVO_OK = 0,
@@ -148,6 +148,56 @@ int psvo_filter_forward(const psvo_desc* desc,
                         const float* obs, const float* eps, const float* u, const int32_t* idx_in,
                         float* X, float* Xanc, float* Fm, float* P1, float* logW, int32_t* idx_out,
                         float* lse, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Forward particle filter with STATE-DEPENDENT diagonal scales: FLAGS.output_cov and FLAGS.diag_cov
+ * (reference src/runner_flag.py:67-70,221-222).  Every MLP then has a second output head (`sigma_layer`,
+ * src/transformation/MLP.py:40-46) and every distribution's scale is
+ *     sigma(input) = sigma_con + 0.1 * (exp(hidden(input) W_sigma + b_sigma) + 1e-6)
+ * (MLP.py:58-61, src/distribution/mvn.py:66-71; sigma_con = the state-independent vector of get_sigma, mvn.py:80-90).
+ * Same loop and outputs as psvo_filter_forward (SVO.SMC, src/SMC/SVO.py:60-180); differences:
+ *  q1, f, g        W2 = [mu_layer | sigma_layer] (H, 2 Dout) row-major, b2 = [b_mu | b_sigma] (2 Dout); one hidden
+ *                  layer (desc->layers <= 1; two layers: PSVO_ERR_UNSUPPORTED).  desc->emission = 1: the reference's
+ *                  tf_poisson drops MLP_g's covariance head (src/distribution/poisson.py:33) -- unit scale, sigc_g unused
+ *  sigc_q1/sigc_f (Dx), sigc_g (Dy)   the sigma_con parts (already clipped); sigc_f ignored when bootstrap
+ *  mu2, sig2 (T,B,Dx)   hoisted q2 mean AND scale per step and sequence; ignored when !two_q
+ *  m0, sig0, fm0, fsig0 (B,Dx)   t = 0 proposal / transition mean and scale per sequence (SVO.py:80-92)
+ *  outputs         as psvo_filter_forward, plus Fs (T,B,Dx,N) = the scale of f given X_t (beside its mean Fm) and
+ *                  P1s (T,B,Dx,N) beside P1 (both required when !bootstrap, ignored otherwise).
+ * ------------------------------------------------------------------------------------------- */
+int psvo_filter_forward_cov(const psvo_desc* desc,
+                            const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
+                            const float* sigc_q1, const float* sigc_f, const float* sigc_g,
+                            const float* mu2, const float* sig2,
+                            const float* m0, const float* sig0, const float* fm0, const float* fsig0,
+                            const float* obs, const float* eps, const float* u, const int32_t* idx_in,
+                            float* X, float* Xanc, float* Fm, float* Fs, float* P1, float* P1s, float* logW,
+                            int32_t* idx_out, float* lse, void* stream);
+
+/* Reverse mode of psvo_filter_forward_cov (TensorFlow autodiff of the loop in the reference, src/trainer.py:115-118).
+ *  inputs  : the forward call's inputs and outputs; upstream gradients dlse (T,B), dFm_ext / dFs_ext (T,B,Dx,N),
+ *            dlogW_ext (T,B,N), each optional (NULL = zero).
+ *  outputs : rows for psvo_mlp_wgrad, one pair per MLP -- w.r.t. the mu_layer output and w.r.t. the RAW sigma_layer
+ *            output (d sigma / d raw = 0.1 exp(raw) already applied): dP / dPs (T,B,Dx,N) for MLP_q1 (which is also f
+ *            when bootstrap), dF / dFs for MLP_f (!bootstrap), dG / dGs (T,B,Dy,N) for MLP_g;
+ *            dmu2, dsig2 (T,B,Dx); dm0, dsig0, dfm0, dfsig0 (B,Dx) (written separately even when the caller passed the
+ *            same buffer as m0 and fm0: add them); dsigc_q1 / dsigc_f (Dx), dsigc_g (Dy) = d loss / d sigma_con.
+ *  ws      : workspace, psvo_filter_cov_ws_floats(B, T, N, Dx, Dy) floats. */
+long long psvo_filter_cov_ws_floats(int B, int T, int N, int Dx, int Dy);
+int psvo_filter_backward_cov(const psvo_desc* desc,
+                             const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
+                             const float* sigc_q1, const float* sigc_f, const float* sigc_g,
+                             const float* mu2, const float* sig2,
+                             const float* m0, const float* sig0, const float* fm0, const float* fsig0,
+                             const float* obs, const float* eps,
+                             const float* X, const float* Fm, const float* Fs, const float* P1, const float* P1s,
+                             const float* logW, const float* lse, const int32_t* idx,
+                             const float* dlse, const float* dFm_ext, const float* dFs_ext, const float* dlogW_ext,
+                             float* dP, float* dPs, float* dF, float* dFs, float* dG, float* dGs,
+                             float* dmu2, float* dsig2,
+                             float* dm0, float* dsig0, float* dfm0, float* dfsig0,
+                             float* dsigc_q1, float* dsigc_f, float* dsigc_g,
+                             float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward simulation with proposal.  Replaces PSVO.backward_simulation_w_proposal

@@ -28,6 +28,10 @@ class PSVO(SVO):
         """PSVO.py:21-50.  Extra `noise` keys: eps_b (T,B,Dx,N,M), u_b (T,B,N) or sel_b (T,B,N) int32."""
         batch_size, time, _ = obs.shape
         self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
+        if self.model.output_cov:
+            raise NotImplementedError("output_cov (state-dependent scales) is built for the forward filter objectives "
+                                      "(SVO / AESMC / IWAE: psvo_filter_forward_cov); the backward simulation with per-particle "
+                                      "transition scales has no kernel yet and there is no fallback path")
 
         log = {}
         # the filter (one workgroup per sequence) is issued on a side stream and overlaps with the encoder,

@@ -9,7 +9,7 @@ permutes the result to the reference's (batch, time, particles, Dx).
 import torch
 
 from .. import ops
-from ..autograd import FilterFunction
+from ..autograd import FilterCovFunction, FilterFunction
 
 
 class SVO:
@@ -178,6 +178,8 @@ class SVO:
             # whenever use_2_q is set (runner.py:38-39)
             raise NotImplementedError("q_uses_true_X is a debugging aid outside the MI355X hot-path scope")
         model = self.model
+        if model.output_cov:
+            return self._SMC_cov(obs, noise)
         Dx, T, N, B = self.Dx, self.time, self.n_particles, self.batch_size
         dev = obs.device
         noise = noise or {}
@@ -229,6 +231,65 @@ class SVO:
             desc, obs_TB, eps, u, idx_in,
             *first, self._sigma(self.q1), sig_q2, sig_f, self._sigma(self.g), mu2, m0, sig0, fm0, fsig0, *extra)
         return {"lse": lse, "Fm": Fm, "logW": logW, "X": X, "Xanc": Xanc, "idx": idx, "eps": eps, "u": u}
+
+    def _mlp_params_cov(self, tran):
+        """(W1, b1, W_mu, b_mu, W_sigma, b_sigma) of a per-particle MLP with the covariance head, at the kernels' width"""
+        W1, b1, Wm, bm, Ws, bs = tran.hip_params_cov()
+        pad = self._kernel_width()[0] - W1.shape[1]
+        if pad:
+            F = torch.nn.functional
+            W1, b1 = F.pad(W1, (0, pad)), F.pad(b1, (0, pad))
+            Wm, Ws = F.pad(Wm, (0, 0, 0, pad)), F.pad(Ws, (0, 0, 0, pad))
+        return W1, b1, Wm, bm, Ws, bs
+
+    def _SMC_cov(self, obs, noise):
+        """SVO.SMC with state-dependent diagonal scales (FLAGS.output_cov and FLAGS.diag_cov; src/transformation/MLP.py:40-46,
+        58-61, src/distribution/mvn.py:66-71): psvo_filter_forward_cov / psvo_filter_backward_cov.  The hoisted distributions
+        (q0, q2 and, outside the default wiring, f on the X0 feature) hand over mean AND scale per row; the per-particle
+        MLPs carry their second head into the kernel."""
+        model = self.model
+        Dx, T, N, B = self.Dx, self.time, self.n_particles, self.batch_size
+        dev = obs.device
+        noise = noise or {}
+        if self._kernel_width()[2] != 1:
+            raise ValueError("output_cov with two hidden layers per particle MLP: the state-dependent-scale kernels take one "
+                             "hidden layer (psvo_filter_forward_cov); no fallback path exists")
+
+        preprocessed_X0, preprocessed_obs = self.preprocess_obs(obs)
+        both = model.use_bootstrap and model.use_2_q
+        obs_TB = obs.transpose(0, 1).contiguous().float()
+        self._obs_TB = obs_TB
+        self.preprocessed_X0, self.preprocessed_obs = preprocessed_X0, preprocessed_obs
+
+        m0, sig0 = self.q0.mean_and_sigma(preprocessed_X0, self._sigma(self.q0))            # (B, Dx) each
+        if both:
+            fm0, fsig0 = m0, sig0
+        else:
+            fm0, fsig0 = self.f.mean_and_sigma(preprocessed_X0, self._sigma(self.f))        # SVO.py:91-92
+        mu2 = sig2 = None
+        if model.use_2_q:
+            if preprocessed_obs is obs:
+                mu2, sig2 = self.q2.mean_and_sigma(obs_TB, self._sigma(self.q2))            # (T, B, Dx)
+            else:
+                mu2, sig2 = (v.transpose(0, 1).contiguous()
+                             for v in self.q2.mean_and_sigma(preprocessed_obs, self._sigma(self.q2)))
+
+        eps = noise.get("eps_f")
+        if eps is None:
+            eps = self._randn(T, B, Dx, N, device=dev)
+        u, idx_in = noise.get("u_f"), noise.get("idx_f")
+        if self.resample_particles and u is None and idx_in is None:
+            u = self._rand(T, B, N, device=dev)
+
+        q1p = self._mlp_params_cov(model.q1_tran)
+        fp = (None,) * 6 if model.use_bootstrap else self._mlp_params_cov(model.f_tran)
+        gp = self._mlp_params_cov(model.g_tran)
+        self._m0, self._sig0 = m0, sig0
+        lse, Fm, Fs, logW, X, Xanc, idx = FilterCovFunction.apply(
+            self._desc(), obs_TB, eps, u, idx_in, *q1p, *fp, *gp,
+            self._sigma(self.q1), None if model.use_bootstrap else self._sigma(self.f), self._sigma(self.g),
+            mu2, sig2, m0, sig0.expand(B, Dx), fm0, fsig0.expand(B, Dx))
+        return {"lse": lse, "Fm": Fm, "Fs": Fs, "logW": logW, "X": X, "Xanc": Xanc, "idx": idx, "eps": eps, "u": u}
 
     def compute_log_ZSMC(self, lse):
         """SVO.py:302-311: mean_b sum_t logsumexp_n log_Ws[t, n, b]; `lse` (T, B) is the per-step

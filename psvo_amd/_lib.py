@@ -45,6 +45,9 @@ SIGNATURES = {
     "psvo_filter_acc_size": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "psvo_filter_ws_floats": (ctypes.c_longlong, [ctypes.c_int] * 5),
     "psvo_filter_backward": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 18 + [ctypes.c_int] + [_P] * 16),
+    "psvo_filter_forward_cov": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 22 + [_P]),
+    "psvo_filter_cov_ws_floats": (ctypes.c_longlong, [ctypes.c_int] * 5),
+    "psvo_filter_backward_cov": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 39 + [_P]),
     "psvo_mlp_wgrad_blocks": (ctypes.c_int, [ctypes.c_longlong]),
     "psvo_mlp_wgrad": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       _P, _P, _MLP, _P, _P, ctypes.c_int, _P]),

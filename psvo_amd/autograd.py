@@ -280,6 +280,46 @@ class FilterFunction(torch.autograd.Function):
             None if same_s else r["dfsig0"]) + gextra
 
 
+class FilterCovFunction(torch.autograd.Function):
+    """psvo_filter_forward_cov / psvo_filter_backward_cov: the forward filter with state-dependent diagonal scales
+    (FLAGS.output_cov and FLAGS.diag_cov).
+
+    apply(desc, obs_TB, eps, u, idx_in,
+          q1 (W1, b1, W_mu, b_mu, W_sigma, b_sigma), f (6 tensors, None x 6 when desc.bootstrap), g (6 tensors),
+          sigc_q1, sigc_f, sigc_g, mu2, sig2, m0, sig0, fm0, fsig0)
+      -> lse (T,B), Fm, Fs (T,B,Dx,N), logW (T,B,N)   [differentiable]
+         X, Xanc (T,B,Dx,N), idx (T,B,N) int32          [constants]
+    One stream, gradients returned as tensors (no in-place accumulation into the flat buffer): this wiring is off the
+    headline path."""
+
+    @staticmethod
+    def forward(ctx, desc, obs_TB, eps, u, idx_in, *t):
+        ctx.set_materialize_grads(False)
+        t = [_cf(v) for v in t]
+        q1, f, g = tuple(t[0:6]), tuple(t[6:12]), tuple(t[12:18])
+        if desc.bootstrap:
+            f = None
+        rest = t[18:27]
+        filt = ops.filter_forward_cov(desc, q1, f, g, *rest, obs_TB, eps, u, idx_in)
+        ctx.desc, ctx.filt = desc, _aliases(filt)
+        ctx.saved = (q1, f, g, rest, obs_TB, eps)
+        ctx.mark_non_differentiable(filt["X"], filt["Xanc"], filt["idx"])
+        return filt["lse"], filt["Fm"], filt["Fs"], filt["logW"], filt["X"], filt["Xanc"], filt["idx"]
+
+    @staticmethod
+    def backward(ctx, dlse, dFm, dFs, dlogW, *_):
+        desc = ctx.desc
+        q1, f, g, rest, obs_TB, eps = ctx.saved
+        r = ops.filter_backward_cov(desc, q1, f, g, *rest, obs_TB, eps, ctx.filt, dlse=_cg(dlse), dFm=_cg(dFm),
+                                    dFs=_cg(dFs), dlogW=_cg(dlogW))
+        two_q, boot = bool(desc.two_q), bool(desc.bootstrap)
+        none6 = (None,) * 6
+        return (None, None, None, None, None) + r["gq1"] + (none6 if boot else r["gf"]) + r["gg"] + (
+            r["dsigc_q1"], None if boot else r["dsigc_f"], r["dsigc_g"],
+            r["dmu2"] if two_q else None, r["dsig2"] if two_q else None,
+            r["dm0"], r["dsig0"], r["dfm0"], r["dfsig0"])
+
+
 def _filter_node_of(Fm, ov):
     """the FilterFunction node that produced `Fm` in this evaluation (its ctx), if the overlap wiring is on: the
     backward-simulation node may launch that node's reverse kernel early.  (A downstream reference only: this node

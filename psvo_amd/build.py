@@ -15,7 +15,7 @@ LIB = os.path.join(CSRC, "libpsvo_hip.so")
 SOURCES = ["psvowr_bwd_l2.hip", "psvowr_bwd.hip", "bsim_bwd_dx4_l2.hip", "bsim_fwd_l2.hip", "bsim_fwd.hip",
            "bsim_bwd_dx2_l2.hip", "bsim_bwd_dx3_l2.hip", "psvowr_fwd.hip", "psvowr_fwd_l2.hip", "bsim_bwd_dx4.hip",
            "bsim_bwd_dx2.hip", "bsim_bwd_dx3.hip", "filter_bwd_l2.hip", "bsim_bwd2_dx2.hip", "filter_bwd.hip",
-           "filter_fwd_l2.hip", "filter_fwd.hip", "bsim_bwd2_dx4.hip", "bsim_bwd2_dx3.hip", "mlp_grad.hip", "lstm_bwd.hip",
+           "filter_fwd_l2.hip", "filter_cov.hip", "filter_fwd.hip", "bsim_bwd2_dx4.hip", "bsim_bwd2_dx3.hip", "mlp_grad.hip", "lstm_bwd.hip",
            "lstm.hip", "rows_mlp.hip", "bsim_bwd.hip", "api.hip", "dense.hip", "adam.hip"]
 HEADERS = ["common.h", "mlp2_valu.h", os.path.join("..", "..", "include", "psvo_hip.h")]      # every unit includes these
 # headers only some units include (a change of bsim_bwd2_impl.h rebuilds 4 units, not 27)

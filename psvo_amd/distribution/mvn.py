@@ -1,7 +1,8 @@
 """tf_mvn -- mirror of reference src/distribution/mvn.py:23-117, diagonal branch.
 
 mean = MLP(Input); scale = max(softplus(sigma_con), sigma_min) with sigma_con a trainable
-state-independent vector (mvn.py:80-90).  The per-particle evaluations run inside the HIP
+state-independent vector (mvn.py:80-90), plus 0.1 * cov(Input) when the transformation has the diagonal
+covariance head (output_cov and diag_cov, mvn.py:66-71).  The per-particle evaluations run inside the HIP
 kernels; this module serves the hoisted per-(b, t) calls and the k-step prediction.
 """
 import math
@@ -52,10 +53,19 @@ class tf_mvn(nn.Module):
         s = torch.where(torch.isnan(s), torch.zeros_like(s), s)
         return torch.clamp(s, min=float(self.sigma_min))
 
+    def mean_and_sigma(self, Input, sigma_con=None):
+        """(mean, scale) of the distribution given Input (get_mvn_from_transformation, mvn.py:51-71, diagonal branches);
+        sigma_con: this distribution's clipped scale vector when the caller already has it (SSM.sigmas())."""
+        mu, cov = self.transformation.transform(Input)
+        sigma = self.get_sigma(mu) if sigma_con is None else sigma_con
+        if cov is not None:
+            assert cov.shape == mu.shape, "diagonal covariance head only"
+            sigma = sigma + 0.1 * cov
+        return mu, sigma
+
     def get_mvn(self, Input):
-        mu, sigma = self.transformation.transform(Input)
-        assert sigma is None
-        return MultivariateNormalDiag(mu, self.get_sigma(mu))
+        mu, sigma = self.mean_and_sigma(Input)
+        return MultivariateNormalDiag(mu, sigma)
 
     def sample_and_log_prob(self, Input, sample_shape=(), name=None, eps=None):
         mvn = self.get_mvn(Input)
@@ -68,6 +78,5 @@ class tf_mvn(nn.Module):
     def mean(self, Input, name=None):
         # (mvn.py:104-117 builds the distribution and takes its mean: the scale plays no part, so its four small
         #  kernels are not launched -- the hoisted networks call this several times per step)
-        mu, sigma = self.transformation.transform(Input)
-        assert sigma is None
+        mu, _ = self.transformation.transform(Input)
         return mu

@@ -247,6 +247,8 @@ class SSM(nn.Module):
             tr = d.transformation
             out = {"layers": [(cv(W), cv(b)) for W, b in zip(tr.kernels, tr.biases)],
                    "mu": (cv(tr.mu_kernel), cv(tr.mu_bias))}
+            if tr.output_cov:                                # sigma_layer (MLP.py:40-46)
+                out["sigma"] = (cv(tr.sigma_kernel), cv(tr.sigma_bias))
             if isinstance(d, tf_mvn):                        # (tf_poisson has no scale variable)
                 out.update({"sigma_raw": cv(d.sigma_con), "sigma_min": float(d.sigma_min)})
             return out
@@ -284,6 +286,8 @@ class SSM(nn.Module):
             for (W, b), (Ws, bs) in zip(zip(tr.kernels, tr.biases), p["layers"]):
                 put(W, Ws); put(b, bs)
             put(tr.mu_kernel, p["mu"][0]); put(tr.mu_bias, p["mu"][1])
+            if tr.output_cov:
+                put(tr.sigma_kernel, p["sigma"][0]); put(tr.sigma_bias, p["sigma"][1])
             if isinstance(d, tf_mvn):
                 put(d.sigma_con, p["sigma_raw"])
                 d.sigma_min = float(p["sigma_min"])

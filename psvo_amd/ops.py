@@ -449,6 +449,106 @@ def filter_backward(desc, q1, f, g, sig_q1, sig_q2, sig_f, sig_g, mu2, m0, sig0,
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# state-dependent scales (FLAGS.output_cov and FLAGS.diag_cov): psvo_filter_forward_cov / psvo_filter_backward_cov.
+# A per-particle MLP is the 6-tuple (W1, b1, W_mu, b_mu, W_sigma, b_sigma); the kernels take the two heads as one output
+# layer, W2 = [W_mu | W_sigma] (H, 2 Dout).
+# ---------------------------------------------------------------------------------------------
+def _cov_struct(p, Din, H, Dout, name):
+    """(psvo_mlp with the concatenated output layer, the tensors that must stay alive until the launch has been issued)"""
+    W1, b1, Wm, bm, Ws, bs = p
+    _chk(Wm, (H, Dout), name + ".W_mu"); _chk(bm, (Dout,), name + ".b_mu")
+    _chk(Ws, (H, Dout), name + ".W_sigma"); _chk(bs, (Dout,), name + ".b_sigma")
+    if _LAUNCH_STREAM is not None:
+        with torch.cuda.stream(_LAUNCH_STREAM):
+            W2, b2 = torch.cat([Wm, Ws], dim=1).contiguous(), torch.cat([bm, bs]).contiguous()
+    else:
+        W2, b2 = torch.cat([Wm, Ws], dim=1).contiguous(), torch.cat([bm, bs]).contiguous()
+    return _mlp_struct((W1, b1, W2, b2), Din, H, 2 * Dout, name), (W2, b2)
+
+
+def filter_forward_cov(desc, q1, f, g, sigc_q1, sigc_f, sigc_g, mu2, sig2, m0, sig0, fm0, fsig0, obs, eps,
+                       u=None, idx_in=None):
+    """psvo_filter_forward_cov.  Returns dict(X, Xanc, Fm, Fs, P1, P1s, logW, idx, lse)."""
+    lib = _lib.load()
+    B, T, N, Dx, Dy, H = desc.B, desc.T, desc.N, desc.Dx, desc.Dy, desc.H
+    dev = eps.device
+    q1s, k1 = _cov_struct(q1, Dx, H, Dx, "q1")
+    fs, k2 = (None, None) if desc.bootstrap else _cov_struct(f, Dx, H, Dx, "f")
+    gs, k3 = _cov_struct(g, Dx, H, Dy, "g")
+    _chk(sigc_q1, (Dx,), "sigc_q1"); _chk(sigc_g, (Dy,), "sigc_g")
+    if desc.two_q:
+        _chk(mu2, (T, B, Dx), "mu2"); _chk(sig2, (T, B, Dx), "sig2")
+    if not desc.bootstrap:
+        _chk(sigc_f, (Dx,), "sigc_f")
+    for t, nm in ((m0, "m0"), (sig0, "sig0"), (fm0, "fm0"), (fsig0, "fsig0")):
+        _chk(t, (B, Dx), nm)
+    _chk(obs, (T, B, Dy), "obs"); _chk(eps, (T, B, Dx, N), "eps")
+    _chk(u, (T, B, N), "u"); _chk(idx_in, (T, B, N), "idx_in", torch.int32)
+    if desc.resample and u is None and idx_in is None:
+        raise ValueError("resampling needs uniforms `u` or teacher-forced `idx_in`")
+    z = lambda *s: _empty(*s, device=dev)
+    out = {"X": z(T, B, Dx, N), "Xanc": z(T, B, Dx, N), "Fm": z(T, B, Dx, N), "Fs": z(T, B, Dx, N), "logW": z(T, B, N),
+           "idx": _empty(T, B, N, device=dev, dtype=torch.int32), "lse": z(T, B),
+           "P1": None if desc.bootstrap else z(T, B, Dx, N), "P1s": None if desc.bootstrap else z(T, B, Dx, N)}
+    _mark("psvo_filter_forward_cov", 0)
+    st = lib.psvo_filter_forward_cov(
+        ctypes.byref(desc), ctypes.byref(q1s), ctypes.byref(fs) if fs is not None else None, ctypes.byref(gs),
+        _ptr(sigc_q1), _ptr(sigc_f), _ptr(sigc_g), _ptr(mu2), _ptr(sig2), _ptr(m0), _ptr(sig0), _ptr(fm0), _ptr(fsig0),
+        _ptr(obs), _ptr(eps), _ptr(u), _ptr(idx_in),
+        _ptr(out["X"]), _ptr(out["Xanc"]), _ptr(out["Fm"]), _ptr(out["Fs"]), _ptr(out["P1"]), _ptr(out["P1s"]),
+        _ptr(out["logW"]), _ptr(out["idx"]), _ptr(out["lse"]), _stream())
+    _mark("psvo_filter_forward_cov", 1)
+    _lib.check(st, "psvo_filter_forward_cov")
+    del k1, k2, k3
+    return out
+
+
+def filter_backward_cov(desc, q1, f, g, sigc_q1, sigc_f, sigc_g, mu2, sig2, m0, sig0, fm0, fsig0, obs, eps, filt,
+                        dlse=None, dFm=None, dFs=None, dlogW=None):
+    """psvo_filter_backward_cov + two psvo_mlp_wgrad launches per MLP (one per head; both contribute to dW1 / db1).
+    Returns a dict of gradients; the MLP entries gq1 / gf / gg are 6-tuples in the order of the MLP tuples."""
+    lib = _lib.load()
+    B, T, N, Dx, Dy, H = desc.B, desc.T, desc.N, desc.Dx, desc.Dy, desc.H
+    dev = eps.device
+    boot = bool(desc.bootstrap)
+    q1s, k1 = _cov_struct(q1, Dx, H, Dx, "q1")
+    fs, k2 = (None, None) if boot else _cov_struct(f, Dx, H, Dx, "f")
+    gs, k3 = _cov_struct(g, Dx, H, Dy, "g")
+    _chk(dlse, (T, B), "dlse"); _chk(dFm, (T, B, Dx, N), "dFm"); _chk(dFs, (T, B, Dx, N), "dFs")
+    _chk(dlogW, (T, B, N), "dlogW")
+    z = lambda *s: _empty(*s, device=dev)
+    rows = lambda D: (z(T, B, D, N), z(T, B, D, N))
+    out = {"dP": rows(Dx), "dF": (None, None) if boot else rows(Dx), "dG": rows(Dy),
+           "dmu2": z(T, B, Dx) if desc.two_q else None, "dsig2": z(T, B, Dx) if desc.two_q else None,
+           "dm0": z(B, Dx), "dsig0": z(B, Dx), "dfm0": z(B, Dx), "dfsig0": z(B, Dx),
+           "dsigc_q1": z(Dx), "dsigc_f": None if boot else z(Dx), "dsigc_g": z(Dy)}
+    ws = z(lib.psvo_filter_cov_ws_floats(B, T, N, Dx, Dy))
+    _mark("psvo_filter_backward_cov", 0)
+    st = lib.psvo_filter_backward_cov(
+        ctypes.byref(desc), ctypes.byref(q1s), ctypes.byref(fs) if fs is not None else None, ctypes.byref(gs),
+        _ptr(sigc_q1), _ptr(sigc_f), _ptr(sigc_g), _ptr(mu2), _ptr(sig2), _ptr(m0), _ptr(sig0), _ptr(fm0), _ptr(fsig0),
+        _ptr(obs), _ptr(eps), _ptr(filt["X"]), _ptr(filt["Fm"]), _ptr(filt["Fs"]), _ptr(filt["P1"]), _ptr(filt["P1s"]),
+        _ptr(filt["logW"]), _ptr(filt["lse"]), _ptr(filt["idx"]), _ptr(dlse), _ptr(dFm), _ptr(dFs), _ptr(dlogW),
+        _ptr(out["dP"][0]), _ptr(out["dP"][1]), _ptr(out["dF"][0]), _ptr(out["dF"][1]), _ptr(out["dG"][0]),
+        _ptr(out["dG"][1]), _ptr(out["dmu2"]), _ptr(out["dsig2"]), _ptr(out["dm0"]), _ptr(out["dsig0"]), _ptr(out["dfm0"]),
+        _ptr(out["dfsig0"]), _ptr(out["dsigc_q1"]), _ptr(out["dsigc_f"]), _ptr(out["dsigc_g"]), _ptr(ws), _stream())
+    _mark("psvo_filter_backward_cov", 1)
+    _lib.check(st, "psvo_filter_backward_cov")
+    del k1, k2, k3
+
+    def head_grads(p, rows_pair, Dout):
+        """[W1 | b1 | W_head | b_head] of each head from its rows -> (dW1, db1, dW_mu, db_mu, dW_sigma, db_sigma)"""
+        W1, b1, Wm, bm, Ws, bs = p
+        gm = split_mlp_grad(mlp_wgrad(filt["X"], rows_pair[0], (W1, b1, Wm, bm), Dx, H, Dout), Dx, H, Dout)
+        gs_ = split_mlp_grad(mlp_wgrad(filt["X"], rows_pair[1], (W1, b1, Ws, bs), Dx, H, Dout), Dx, H, Dout)
+        return (gm[0] + gs_[0], gm[1] + gs_[1], gm[2], gm[3], gs_[2], gs_[3])
+    out["gq1"] = head_grads(q1, out["dP"], Dx)
+    out["gf"] = None if boot else head_grads(f, out["dF"], Dx)
+    out["gg"] = head_grads(g, out["dG"], Dy)
+    return out
+
+
 def _chain_rows(out, z, T, B, Dx, N):
     """per-chain rows of d bmu2 (T,B,Dx,N), d minit and d imean (B,Dx,N) in ONE buffer, so that one reduction over the
     chains serves all three (they sit on the dependent chain in front of the encoder BPTT)"""

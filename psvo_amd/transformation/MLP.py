@@ -1,4 +1,6 @@
-"""MLP_transformation -- mirror of reference src/transformation/MLP.py:8-86 (output_cov=False).
+"""MLP_transformation -- mirror of reference src/transformation/MLP.py:8-86, incl. the diagonal covariance head
+(output_cov and diag_cov: `sigma_layer`, MLP.py:40-46,58-61); the full-covariance head (output_cov without diag_cov) is out of
+scope.
 
 Weights keep the keras Dense layout (kernel (in, out), y = x @ kernel + bias) so they can be
 handed to the HIP kernels (psvo_mlp in include/psvo_hip.h) without a transpose.
@@ -22,9 +24,10 @@ class MLP_transformation(nn.Module):
     def __init__(self, Dhs, Dout, Din, use_residual=False, output_cov=False, diag_cov=False,
                  name="MLP_transformation"):
         super().__init__()
-        if output_cov:
-            # reference MLP.py:40-46,60-66: state-dependent covariance head -- not on the BASELINE path
-            raise NotImplementedError("output_cov=True is outside the MI355X hot-path scope (SURVEY section 8f-4)")
+        if output_cov and not diag_cov:
+            # reference MLP.py:41,63-66: Dout^2 outputs reshaped to a matrix, cov = A A^T -> MultivariateNormalFullCovariance
+            raise NotImplementedError("output_cov without diag_cov (full covariance) is outside the MI355X hot-path scope "
+                                      "(SURVEY.md section 2 row 2); output_cov with diag_cov is built")
         self.Dhs, self.Dout, self.Din = list(Dhs), Dout, Din
         self.use_residual = use_residual
         self.output_cov, self.diag_cov = output_cov, diag_cov
@@ -38,6 +41,9 @@ class MLP_transformation(nn.Module):
             d = Dh
         self.mu_kernel = nn.Parameter(_he_normal_(torch.empty(d, Dout)))   # mu_layer: Dense(linear)
         self.mu_bias = nn.Parameter(torch.zeros(Dout))
+        if output_cov:                                     # sigma_layer: Dense(linear, he_normal, bias Constant(1.0)), MLP.py:40-46
+            self.sigma_kernel = nn.Parameter(_he_normal_(torch.empty(d, Dout)))
+            self.sigma_bias = nn.Parameter(torch.ones(Dout))
 
     # limits of the fused one-hidden-layer row kernels (psvo_rows_mlp_*, csrc/rows_mlp.hip); anything else that is a plain
     # chain of Dense layers goes layer by layer through psvo_dense_* (csrc/dense.hip, f32 MFMA)
@@ -45,6 +51,8 @@ class MLP_transformation(nn.Module):
 
     def _native_refusal(self, Input):
         """why the fused psvo_rows_mlp_* pair cannot evaluate this MLP on `Input` (None if it can)"""
+        if self.output_cov:
+            return "two output heads (mu_layer, sigma_layer)"
         if len(self.Dhs) != 1:
             return "%d hidden layers %s (the fused kernels take exactly one)" % (len(self.Dhs), self.Dhs)
         if self.use_residual:
@@ -60,7 +68,8 @@ class MLP_transformation(nn.Module):
         return None
 
     def transform(self, Input):
-        """reference MLP.py:48-68; returns (mu, None).
+        """reference MLP.py:48-68; returns (mu, cov): cov = None without the covariance head, else exp(sigma_layer(hidden)) + 1e-6
+        (diag_cov; MLP.py:58-61).
 
         Tensors in HBM go through native kernels only: the fused one-hidden-layer pair psvo_rows_mlp_* where it applies
         (one launch forward, one backward), otherwise one psvo_dense_* launch per Dense layer (any number of hidden layers,
@@ -81,7 +90,11 @@ class MLP_transformation(nn.Module):
                 mu = DenseFunction.apply(hidden, self.mu_kernel, self.mu_bias, False)
                 if self.use_residual:
                     mu = mu + X
-                return mu.reshape(Input.shape[:-1] + (mu.shape[-1],)), None
+                cov = None
+                if self.output_cov:
+                    cov = torch.exp(DenseFunction.apply(hidden, self.sigma_kernel, self.sigma_bias, False)) + 1e-6
+                    cov = cov.reshape(Input.shape[:-1] + (cov.shape[-1],))
+                return mu.reshape(Input.shape[:-1] + (mu.shape[-1],)), cov
             from ..autograd import RowsMLPFunction
             mu = RowsMLPFunction.apply(self.__dict__.get("_flat_grad"), X, self.kernels[0], self.biases[0],
                                        self.mu_kernel, self.mu_bias)
@@ -92,7 +105,10 @@ class MLP_transformation(nn.Module):
         mu = hidden @ self.mu_kernel + self.mu_bias
         if self.use_residual:
             mu = mu + Input
-        return mu, None
+        cov = None
+        if self.output_cov:
+            cov = torch.exp(hidden @ self.sigma_kernel + self.sigma_bias) + 1e-6
+        return mu, cov
 
     def hip_params(self):
         """the per-particle form the persistent kernels take: (W1, b1, W2, b2) for one hidden layer,
@@ -106,6 +122,15 @@ class MLP_transformation(nn.Module):
             p = p + (self.kernels[1], self.biases[1])
         return p
 
+    def hip_params_cov(self):
+        """the per-particle form of the state-dependent-scale kernels (psvo_filter_forward_cov): (W1, b1, W_mu, b_mu, W_sigma,
+        b_sigma), one hidden layer; the kernels take the two heads as ONE output layer [mu_layer | sigma_layer]."""
+        if not self.output_cov or len(self.Dhs) != 1 or self.use_residual:
+            raise ValueError("%s: the state-dependent-scale kernels take one hidden layer, two heads and no residual "
+                             "connection, got layers %s, output_cov=%s, use_residual=%s (no fallback path exists)"
+                             % (self.name, self.Dhs, self.output_cov, self.use_residual))
+        return (self.kernels[0], self.biases[0], self.mu_kernel, self.mu_bias, self.sigma_kernel, self.sigma_bias)
+
     def get_variables(self):
         """reference MLP.py:70-86."""
         res = {}
@@ -114,4 +139,7 @@ class MLP_transformation(nn.Module):
             res["hidden_{}/bias".format(i)] = b
         res["mu_layer/weights"] = self.mu_kernel
         res["mu_layer/bias"] = self.mu_bias
+        if self.output_cov:
+            res["sigma_layer/weights"] = self.sigma_kernel
+            res["sigma_layer/bias"] = self.sigma_bias
         return res

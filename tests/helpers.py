@@ -60,6 +60,10 @@ def perturb_(model, seed=7, scale=0.3):
         for name, p in model.named_parameters():
             if name.endswith("bias") or "biases" in name:
                 p.copy_(torch.randn(p.shape, generator=g) * scale)
+            if name.endswith("sigma_bias"):     # covariance head (output_cov): keep it around its Constant(1.0) initialiser
+                p.add_(1.0)
+            if name.endswith("sigma_kernel"):   # ... and its he_normal kernel small: scale = con + 0.1 exp(h W + b) feeds the
+                p.mul_(0.25)                    # next state, and without a q2 term a random model runs away to inf in 2 steps
             if name.endswith("sigma_con"):
                 p.copy_(0.5 + 1.5 * torch.rand(p.shape, generator=g))
     return model

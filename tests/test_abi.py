@@ -30,7 +30,7 @@ def test_header_symbols_are_exported_and_bound(built_lib):
 def test_version_and_status_strings(built_lib):
     from psvo_amd import _lib
     lib = _lib.load()
-    assert lib.psvo_abi_version() == 5      # (4: psvo_desc.layers, psvo_mlp.Wh / bh, psvo_mlp2_wgrad; 5: dlse of psvo_bsim_backward_fold)
+    assert lib.psvo_abi_version() == 6      # (4: psvo_desc.layers, psvo_mlp.Wh / bh, psvo_mlp2_wgrad; 5: dlse of psvo_bsim_backward_fold; 6: *_cov)
     assert lib.psvo_status_string(0) == b"ok"
     assert b"unsupported" in lib.psvo_status_string(_lib.PSVO_ERR_UNSUPPORTED)
     assert lib.psvo_filter_acc_size(2, 1) == 21 and lib.psvo_bsim_acc_size(3, 2) == 23
@@ -65,12 +65,20 @@ def test_invalid_arguments_are_rejected_without_a_device(built_lib):
         assert lib.psvo_filter_forward(ctypes.byref(d), None, None, None, *nul, None) == _lib.PSVO_ERR_UNSUPPORTED
         assert lib.psvo_bsim_blocks(ctypes.byref(d)) == _lib.PSVO_ERR_UNSUPPORTED
         for name in ("psvo_filter_backward", "psvo_bsim_forward", "psvo_bsim_backward", "psvo_bsimwr_forward",
-                     "psvo_bsimwr_backward"):
+                     "psvo_bsimwr_backward", "psvo_filter_forward_cov", "psvo_filter_backward_cov"):
             fn = getattr(lib, name)
             null = lambda ty: 0 if ty in (ctypes.c_int, ctypes.c_longlong) else 0.0 if ty in (ctypes.c_float, ctypes.c_double) else None
             args = [ctypes.byref(d)] + [null(ty) for ty in _lib.SIGNATURES[name][1][1:]]
             assert fn(*args) == _lib.PSVO_ERR_UNSUPPORTED, name
-    d.layers = 1
+    # the state-dependent-scale filter (output_cov and diag_cov): one hidden layer
+    nul_cov = lambda name: [None] * (len(_lib.SIGNATURES[name][1]) - 1)
+    for layers, emission, want in ((2, 0, _lib.PSVO_ERR_UNSUPPORTED), (1, 1, _lib.PSVO_ERR_INVALID),
+                                   (1, 0, _lib.PSVO_ERR_INVALID)):
+        d.layers, d.emission = layers, emission
+        for name in ("psvo_filter_forward_cov", "psvo_filter_backward_cov"):
+            assert getattr(lib, name)(ctypes.byref(d), *nul_cov(name)) == want, (name, layers, emission)
+    d.layers, d.emission = 1, 0
+    assert lib.psvo_filter_cov_ws_floats(2, 4, 8, 2, 1) == 2 * 5 + 2 * 4 * 2 * 2 * 8
     with pytest.raises(ValueError):
         _lib.check(_lib.PSVO_ERR_UNSUPPORTED, "x")
     with pytest.raises(_lib.PsvoHipError):

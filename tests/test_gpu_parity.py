@@ -243,6 +243,9 @@ def _pairs(model, P):
             out.append((name + ".b%d" % i, b, P[name]["layers"][i][1]))
         out.append((name + ".Wmu", tr.mu_kernel, P[name]["mu"][0]))
         out.append((name + ".bmu", tr.mu_bias, P[name]["mu"][1]))
+        if "sigma" in P[name]:                      # covariance head (output_cov and diag_cov)
+            out.append((name + ".Wsigma", tr.sigma_kernel, P[name]["sigma"][0]))
+            out.append((name + ".bsigma", tr.sigma_bias, P[name]["sigma"][1]))
         if "sigma_raw" in P[name]:                  # (tf_poisson has no scale variable)
             out.append((name + ".sigma", d.sigma_con, P[name]["sigma_raw"]))
     dist("q0", model.q0_dist); dist("q1", model.q1_dist); dist("g", model.g_dist)
@@ -452,6 +455,45 @@ def test_two_hidden_layers(built_lib, case, extra):
     """two hidden layers per particle MLP (psvo_desc.layers = 2; DEPTH_CASES): values, indices and every gradient
     against the oracle, in all five objectives."""
     _variant_against_oracle(case, extra)
+
+
+# output_cov and diag_cov (src/runner_flag.py:67-70): every MLP carries the sigma_layer head and every scale is state-dependent
+# (src/transformation/MLP.py:40-46,58-61, src/distribution/mvn.py:66-71) -- psvo_filter_forward_cov / _backward_cov.  All four
+# bootstrap / 2q wirings, the three forward-filter objectives, both kernel sizes (<= 256 and 512 threads), padded widths and
+# the Poisson emission (which drops MLP_g's head, src/distribution/poisson.py:33).
+_COV = dict(output_cov=True, diag_cov=True)
+COV_CASES = [
+    (("AESMC", 2, 6, 16, 1, 2, 1, 32, True, True), _COV),
+    (("AESMC", 2, 7, 100, 1, 3, 2, 32, False, True), _COV),
+    (("AESMC", 2, 7, 130, 1, 2, 1, 16, True, False), _COV),
+    (("AESMC", 2, 5, 300, 1, 4, 1, 64, False, False), _COV),
+    (("AESMC", 2, 5, 512, 1, 4, 2, 32, False, True), _COV),
+    (("IWAE", 2, 8, 96, 1, 3, 1, 16, False, True), _COV),
+    (("IWAE", 1, 20, 4, 1, 2, 1, 32, True, True), _COV),
+    (("SVO", 2, 8, 32, 1, 2, 1, 32, True, True), _COV),
+    (("SVO", 2, 6, 16, 1, 3, 1, 32, False, False), _COV),
+    (("SVO", 2, 6, 24, 1, 2, 2, 32, True, True), dict(_COV, q1_layers="24", g_layers="16", q0_layers="20", q2_layers="50")),
+    (("AESMC", 2, 6, 16, 1, 2, 1, 32, True, True), dict(_COV, poisson_emission=True)),
+    (("SVO", 2, 5, 40, 1, 3, 2, 16, False, True), dict(_COV, poisson_emission=True)),
+]
+
+
+@pytest.mark.parametrize("case,extra", COV_CASES, ids=_variant_ids)
+def test_state_dependent_scales(built_lib, case, extra):
+    """output_cov and diag_cov: values, free-running indices and every gradient (both heads of every MLP, sigma_con, the
+    hoisted networks and the encoder behind them) against the oracle."""
+    _variant_against_oracle(case, extra)
+
+
+def test_state_dependent_scales_refusals(built_lib):
+    """what is NOT built says so: the backward-simulation objectives with output_cov, and two hidden layers with output_cov"""
+    FLAGS, model, smc, obs, noise = _setup("PSVO", 2, 5, 8, 4, 2, 1, 32, True, True, **_COV)
+    with pytest.raises(NotImplementedError):
+        smc.get_log_ZSMC(obs.float().cuda(), None, noise=Hh.noise_to_hip(noise, "cuda"))
+    FLAGS, model, smc, obs, noise = _setup("AESMC", 2, 5, 8, 1, 2, 1, 32, True, True, **dict(_COV, q1_layers="32,32",
+                                                                                            g_layers="32,32"))
+    with pytest.raises(ValueError):
+        smc.get_log_ZSMC(obs.float().cuda(), None, noise=Hh.noise_to_hip(noise, "cuda"))
 
 
 def _variant_against_oracle(case, extra):

@@ -346,3 +346,32 @@ def test_quiver_lattice_dictionary():
     o = O.OracleSVO(m.export_reference_layout(torch.float64), Hh.oracle_flags(FLAGS, "SVO"))
     ref = o.get_nextX(torch.as_tensor(d["X"].reshape(-1, 2))).reshape(25, 25, 2).numpy()
     assert np.allclose(d["nextX"], ref, atol=1e-5)
+
+
+def test_covariance_head_mirror_matches_oracle_on_cpu():
+    """output_cov and diag_cov (MLP.py:40-46,58-61, mvn.py:66-71): the sigma_layer head exists on every MLP (bias 1.0),
+    scale = sigma_con + 0.1 (exp(head) + 1e-6), export / import carries it, and the full-covariance form is refused"""
+    from psvo_amd.transformation.MLP import MLP_transformation
+    torch.manual_seed(3)
+    FLAGS = Hh.make_flags("SVO", n_particles=4, output_cov=True, diag_cov=True, use_bootstrap=False)
+    m = SSM(FLAGS)
+    for tr in (m.q0_tran, m.q1_tran, m.q2_tran, m.f_tran, m.g_tran):
+        assert tr.sigma_kernel.shape == tr.mu_kernel.shape and torch.equal(tr.sigma_bias, torch.ones_like(tr.sigma_bias))
+        assert set(tr.get_variables()) >= {"sigma_layer/weights", "sigma_layer/bias"}
+    Hh.perturb_(m)
+    P = m.export_reference_layout(torch.float64)
+    x = torch.randn(5, 3, 2)
+    for name, d in (("q1", m.q1_dist), ("f", m.f_dist), ("g", m.g_dist)):
+        mu, sig = d.mean_and_sigma(x)
+        mu_ref, sig_ref = O.OracleMVN(P[name]).mean_and_sigma(x.double())
+        assert torch.allclose(mu.double(), mu_ref, atol=1e-5) and torch.allclose(sig.double(), sig_ref, atol=1e-5)
+        assert float((sig - d.get_sigma()).min()) > 0.0          # the head adds to sigma_con
+        lp = d.log_prob(x, x + 0.3)
+        assert torch.allclose(lp.double(), O.OracleMVN(P[name]).log_prob(x.double(), x.double() + 0.3), atol=1e-4)
+        assert torch.equal(d.mean(x), mu)
+    b = SSM(FLAGS).load_reference_layout(P)
+    for pa, pb in zip(m.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+    with pytest.raises(NotImplementedError):
+        MLP_transformation([8], 2, 2, output_cov=True, diag_cov=False)
+    assert MLP_transformation([8], 2, 2, output_cov=False, diag_cov=True).transform(x)[1] is None    # MLP.py:40: no head
