@@ -200,6 +200,56 @@ int psvo_filter_backward_cov(const psvo_desc* desc,
                              float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Backward simulation with proposal, STATE-DEPENDENT diagonal scales (FLAGS.output_cov and FLAGS.diag_cov; see
+ * psvo_filter_forward_cov).  Same loop and outputs as psvo_bsim_forward (PSVO.backward_simulation_w_proposal, reference
+ * src/SMC/PSVO.py:69-203); differences:
+ *  Fm, Fs (T,B,Dx,N)   mean AND scale of f given every forward particle (outputs of psvo_filter_forward_cov): the transition
+ *                  tile (PSVO.py:128-133, never materialised) has a scale per forward particle
+ *  f, g, q1_inv    W2 = [mu_layer | sigma_layer] (H, 2 Dout), b2 (2 Dout); one hidden layer; desc->emission = 1 drops MLP_g's
+ *                  covariance head as the reference's tf_poisson does
+ *  sigc_f, sigc_q1inv (Dx), sigc_g (Dy)   the sigma_con parts
+ *  bmu2, bsig2 (T,B,Dx); minit, sinit, imean, isig (B,Dx)   hoisted means and scales per row (BSim_q2; BSim_q_init at
+ *                  t = T-1; the t = 0 prior term f / q0 at mu_0, PSVO.py:169-175)
+ *  saves (all four or none; required by psvo_bsim_backward_cov): lam_all (T,B,N,M) log2-domain filter term, om_all (T,B,N,M)
+ *                  normalised sub-particle log-weights, mu1_all / s1_all (T,B,Dx,N) mean and scale of q1_inv given bwX[t+1].
+ * ------------------------------------------------------------------------------------------- */
+int psvo_bsim_forward_cov(const psvo_desc* desc,
+                          const float* Fm, const float* Fs, const float* logW, const float* lse,
+                          const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
+                          const float* sigc_f, const float* sigc_g, const float* sigc_q1inv,
+                          const float* bmu2, const float* bsig2,
+                          const float* minit, const float* sinit, const float* imean, const float* isig,
+                          const float* obs, const float* eps_b, const float* u_b, const int32_t* sel_in,
+                          float* bwX, float* flp, float* glp, float* Omega, int32_t* sel_out, float* score,
+                          float* lam_all, float* om_all, float* mu1_all, float* s1_all,
+                          void* stream);
+
+/* Reverse mode of psvo_bsim_forward_cov (TensorFlow autodiff of the loop in the reference, src/trainer.py:115-118).
+ *  inputs  : the forward call's inputs, its outputs bwX, sel, the four saves, and dscore (B,N) = d loss / d score.
+ *  outputs : rows for psvo_mlp_wgrad, w.r.t. the mu_layer output and w.r.t. the RAW sigma_layer output of every MLP
+ *            evaluation: xt (T,B,Dx,N,M) sub-particles, dFt / dFts (T,B,Dx,N,M) for MLP_f(x~), dGt / dGts (T,B,Dy,N,M)
+ *            for MLP_g(x~), dmu1 / dmu1s (T,B,Dx,N) for MLP_q1inv(bwX[t+1]);
+ *            ACCUMULATED with float atomics -- the caller zero-fills them: dFm, dFs (T,B,Dx,N), dlogW (T,B,N), dlse (T,B)
+ *            (-> psvo_filter_backward_cov as dFm_ext, dFs_ext, dlogW_ext and added to dlse), dbmu2, dbsig2 (T,B,Dx),
+ *            dminit, dsinit, dimean, disig (B,Dx), dsigc_f, dsigc_q1inv (Dx), dsigc_g (Dy).
+ *  The summation order of the atomics is not fixed: results are reproducible to rounding, not bit for bit. */
+int psvo_bsim_backward_cov(const psvo_desc* desc,
+                           const float* Fm, const float* Fs, const float* logW, const float* lse,
+                           const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
+                           const float* sigc_f, const float* sigc_g, const float* sigc_q1inv,
+                           const float* bmu2, const float* bsig2,
+                           const float* minit, const float* sinit, const float* imean, const float* isig,
+                           const float* obs, const float* eps_b, const float* bwX, const int32_t* sel,
+                           const float* lam_all, const float* om_all, const float* mu1_all, const float* s1_all,
+                           const float* dscore,
+                           float* xt, float* dFt, float* dFts, float* dGt, float* dGts, float* dmu1, float* dmu1s,
+                           float* dFm, float* dFs, float* dlogW, float* dlse,
+                           float* dbmu2, float* dbsig2,
+                           float* dminit, float* dsinit, float* dimean, float* disig,
+                           float* dsigc_f, float* dsigc_g, float* dsigc_q1inv,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Backward simulation with proposal.  Replaces PSVO.backward_simulation_w_proposal
  * (reference src/SMC/PSVO.py:69-203): the (M, N, N, B) transition tile (:128-133) is never
  * materialised -- forward-particle means are staged in LDS and reduced with an online

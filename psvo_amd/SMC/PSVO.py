@@ -7,7 +7,7 @@ import torch
 
 from .. import ops
 from .. import autograd
-from ..autograd import BsimFunction, ElboBsimFunction, Overlap, side_stream
+from ..autograd import BsimCovFunction, BsimFunction, ElboBsimFunction, Overlap, side_stream
 from .SVO import SVO
 
 
@@ -29,9 +29,7 @@ class PSVO(SVO):
         batch_size, time, _ = obs.shape
         self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
         if self.model.output_cov:
-            raise NotImplementedError("output_cov (state-dependent scales) is built for the forward filter objectives "
-                                      "(SVO / AESMC / IWAE: psvo_filter_forward_cov); the backward simulation with per-particle "
-                                      "transition scales has no kernel yet and there is no fallback path")
+            return self._get_log_ZSMC_cov(obs, noise)
 
         log = {}
         # the filter (one workgroup per sequence) is issued on a side stream and overlaps with the encoder,
@@ -51,6 +49,51 @@ class PSVO(SVO):
         log["filter"], log["bsim"] = filt, bs
         self._release()
         return log_ZSMC, log
+
+    def _get_log_ZSMC_cov(self, obs, noise):
+        """get_log_ZSMC with state-dependent diagonal scales (FLAGS.output_cov and FLAGS.diag_cov): psvo_filter_forward_cov,
+        then psvo_bsim_forward_cov on the filter's means AND scales; one stream (no overlap wiring on this path)."""
+        log = {}
+        self._release()
+        self._ov = None
+        self._sigmas = self.model.sigmas()
+        filt = self.SMC(None, obs, noise=noise)
+        bs = self._backward_simulation_cov(filt, obs, noise or {})
+        log_ZSMC = self.compute_log_ZSMC_bsim(bs["score"])
+        log["Xs"] = bs["bwX"].permute(1, 0, 3, 2)
+        log["filter"], log["bsim"] = filt, bs
+        self._release()
+        return log_ZSMC, log
+
+    def _backward_simulation_cov(self, filt, obs, noise):
+        model = self.model
+        Dx, T, N, B = self.Dx, self.time, self.n_particles, self.batch_size
+        M = self.n_particles_for_BSim_proposal
+        dev = obs.device
+        _, preprocessed_obs = self.BS_preprocess_obs(obs)                        # (B, T, 2Dh)
+        bmu2, bsig2 = (v.transpose(0, 1).contiguous()
+                       for v in self.BSim_q2.mean_and_sigma(preprocessed_obs, self._sigma(self.BSim_q2)))    # (T, B, Dx)
+        minit, sinit = self.BSim_q_init.mean_and_sigma(preprocessed_obs[:, -1], self._sigma(self.BSim_q_init))   # (B, Dx)
+        mu_0 = self.preprocessed_X0                                              # cached by SMC()
+        if not (model.use_bootstrap and model.use_2_q):
+            imean, isig = self.f.mean_and_sigma(mu_0, self._sigma(self.f))       # PSVO.py:171
+        else:
+            imean, isig = self._m0, self._sig0                                   # PSVO.py:173: q0's density at mu_0
+        eps_b = noise.get("eps_b")
+        if eps_b is None:
+            eps_b = self._randn(T, B, Dx, N, M, device=dev)
+        u_b, sel_in = noise.get("u_b"), noise.get("sel_b")
+        if u_b is None and sel_in is None:
+            u_b = self._rand(T, B, N, device=dev)
+        obs_TB = getattr(self, "_obs_TB", None)
+        if obs_TB is None or obs_TB.shape[:2] != (T, B):
+            obs_TB = obs.transpose(0, 1).contiguous().float()
+        score, bwX, flp, glp, Omega, sel = BsimCovFunction.apply(
+            self._desc(M), obs_TB, eps_b, u_b, sel_in, filt["Fm"], filt["Fs"], filt["logW"], filt["lse"],
+            *self._mlp_params_cov(model.f_tran), *self._mlp_params_cov(model.g_tran), *self._mlp_params_cov(model.q1_inv_tran),
+            self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv),
+            bmu2, bsig2, minit, sinit.expand(B, Dx), imean, isig.expand(B, Dx))
+        return {"score": score, "bwX": bwX, "flp": flp, "glp": glp, "Omega": Omega, "sel": sel}
 
     def compute_log_ZSMC_bsim(self, score):
         """PSVO.py:52-67: mean_b [ logsumexp_n( sum_t(f+g) - sum_t Omega ) - log N ]."""

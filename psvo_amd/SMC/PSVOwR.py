@@ -21,9 +21,9 @@ class PSVOwR(PSVO):
         batch_size, time, _ = obs.shape
         self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
         if self.model.output_cov:
-            raise NotImplementedError("output_cov (state-dependent scales) is built for the forward filter objectives "
-                                      "(SVO / AESMC / IWAE: psvo_filter_forward_cov); the backward simulation with per-particle "
-                                      "transition scales has no kernel yet and there is no fallback path")
+            raise NotImplementedError("output_cov (state-dependent scales) is built for SVO / AESMC / IWAE / PSVO "
+                                      "(psvo_filter_forward_cov, psvo_bsim_forward_cov); the backward simulation WITH "
+                                      "RESAMPLING has no such kernel and there is no fallback path")
 
         log = {}
         # (second side stream for the bsim weight gradients only in the default wiring: otherwise the hoisted

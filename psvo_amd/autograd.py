@@ -405,6 +405,38 @@ class BsimFunction(torch.autograd.Function):
             r["dminit"], r["dsig_init"], r["dimean"], r["disig"]) + gextra
 
 
+class BsimCovFunction(torch.autograd.Function):
+    """psvo_bsim_forward_cov / psvo_bsim_backward_cov: the backward simulation with state-dependent diagonal scales.
+
+    apply(desc, obs_TB, eps_b, u_b, sel_in, Fm, Fs, logW, lse,
+          f (W1, b1, W_mu, b_mu, W_sigma, b_sigma), g (6 tensors), q1_inv (6 tensors),
+          sigc_f, sigc_g, sigc_q1inv, bmu2, bsig2, minit, sinit, imean, isig)
+      -> score (B,N) [differentiable]; bwX (T,B,Dx,N), flp, glp, Omega (T,B,N), sel (T,B,N) [constants]
+    One stream; gradients returned as tensors."""
+
+    @staticmethod
+    def forward(ctx, desc, obs_TB, eps_b, u_b, sel_in, Fm, Fs, logW, lse, *t):
+        t = [_cf(v) for v in t]
+        f, g, q1_inv = tuple(t[0:6]), tuple(t[6:12]), tuple(t[12:18])
+        rest = t[18:27]
+        filt = {"Fm": _cf(Fm), "Fs": _cf(Fs), "logW": _cf(logW), "lse": _cf(lse)}
+        bs = ops.bsim_forward_cov(desc, filt, f, g, q1_inv, *rest, obs_TB, eps_b, u_b, sel_in,
+                                  save=any(ctx.needs_input_grad))
+        ctx.desc, ctx.filt, ctx.bs = desc, filt, _aliases(bs)
+        ctx.saved = (f, g, q1_inv, rest, obs_TB, eps_b)
+        ctx.mark_non_differentiable(bs["bwX"], bs["flp"], bs["glp"], bs["Omega"], bs["sel"])
+        return bs["score"], bs["bwX"], bs["flp"], bs["glp"], bs["Omega"], bs["sel"]
+
+    @staticmethod
+    def backward(ctx, dscore, *_):
+        desc = ctx.desc
+        f, g, q1_inv, rest, obs_TB, eps_b = ctx.saved
+        r = ops.bsim_backward_cov(desc, ctx.filt, f, g, q1_inv, *rest, obs_TB, eps_b, ctx.bs, _cg(dscore).float())
+        return (None, None, None, None, None, r["dFm"], r["dFs"], r["dlogW"], r["dlse"]) + r["gf"] + r["gg"] + r["gq1inv"] + (
+            r["dsigc_f"], r["dsigc_g"], r["dsigc_q1inv"], r["dbmu2"], r["dbsig2"], r["dminit"], r["dsinit"], r["dimean"],
+            r["disig"])
+
+
 def _note_exchange(desc, ws, bit):
     """OR the launch's exchange-timeout flag (last word of its workspace, cleared by every launch) into the sticky
     device word the objective keeps across launches (PSVOwR.check_exchange reads it): bit 1 = forward, bit 2 = reverse."""

@@ -549,6 +549,94 @@ def filter_backward_cov(desc, q1, f, g, sigc_q1, sigc_f, sigc_g, mu2, sig2, m0, 
     return out
 
 
+def bsim_forward_cov(desc, filt, f, g, q1_inv, sigc_f, sigc_g, sigc_q1inv, bmu2, bsig2, minit, sinit, imean, isig,
+                     obs, eps_b, u_b=None, sel_in=None, save=False):
+    """psvo_bsim_forward_cov.  Returns dict(bwX, flp, glp, Omega, sel, score[, lam, om, mu1, s1])."""
+    lib = _lib.load()
+    B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
+    dev = eps_b.device
+    fs, k1 = _cov_struct(f, Dx, H, Dx, "f")
+    gs, k2 = _cov_struct(g, Dx, H, Dy, "g")
+    qs, k3 = _cov_struct(q1_inv, Dx, H, Dx, "q1_inv")
+    _chk(filt["Fm"], (T, B, Dx, N), "Fm"); _chk(filt["Fs"], (T, B, Dx, N), "Fs")
+    _chk(filt["logW"], (T, B, N), "logW"); _chk(filt["lse"], (T, B), "lse")
+    _chk(sigc_f, (Dx,), "sigc_f"); _chk(sigc_g, (Dy,), "sigc_g"); _chk(sigc_q1inv, (Dx,), "sigc_q1inv")
+    _chk(bmu2, (T, B, Dx), "bmu2"); _chk(bsig2, (T, B, Dx), "bsig2")
+    for t, nm in ((minit, "minit"), (sinit, "sinit"), (imean, "imean"), (isig, "isig")):
+        _chk(t, (B, Dx), nm)
+    _chk(obs, (T, B, Dy), "obs"); _chk(eps_b, (T, B, Dx, N, M), "eps_b")
+    _chk(u_b, (T, B, N), "u_b"); _chk(sel_in, (T, B, N), "sel_in", torch.int32)
+    if u_b is None and sel_in is None:
+        raise ValueError("the backward simulation needs uniforms `u_b` or teacher-forced `sel_in`")
+    z = lambda *s: _empty(*s, device=dev)
+    out = {"bwX": z(T, B, Dx, N), "flp": z(T, B, N), "glp": z(T, B, N), "Omega": z(T, B, N),
+           "sel": _empty(T, B, N, device=dev, dtype=torch.int32), "score": z(B, N),
+           "lam": z(T, B, N, M) if save else None, "om": z(T, B, N, M) if save else None,
+           "mu1": z(T, B, Dx, N) if save else None, "s1": z(T, B, Dx, N) if save else None}
+    _mark("psvo_bsim_forward_cov", 0)
+    st = lib.psvo_bsim_forward_cov(
+        ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["Fs"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
+        ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs), _ptr(sigc_f), _ptr(sigc_g), _ptr(sigc_q1inv),
+        _ptr(bmu2), _ptr(bsig2), _ptr(minit), _ptr(sinit), _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(u_b),
+        _ptr(sel_in), _ptr(out["bwX"]), _ptr(out["flp"]), _ptr(out["glp"]), _ptr(out["Omega"]), _ptr(out["sel"]),
+        _ptr(out["score"]), _ptr(out["lam"]), _ptr(out["om"]), _ptr(out["mu1"]), _ptr(out["s1"]), _stream())
+    _mark("psvo_bsim_forward_cov", 1)
+    _lib.check(st, "psvo_bsim_forward_cov")
+    del k1, k2, k3
+    return out
+
+
+def bsim_backward_cov(desc, filt, f, g, q1_inv, sigc_f, sigc_g, sigc_q1inv, bmu2, bsig2, minit, sinit, imean, isig,
+                      obs, eps_b, bs, dscore):
+    """psvo_bsim_backward_cov + two psvo_mlp_wgrad launches per MLP (one per head).  `bs` = the forward call's outputs with
+    its saves.  Returns a dict of gradients; gf / gg / gq1inv are 6-tuples in the order of the MLP tuples."""
+    lib = _lib.load()
+    B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
+    dev = eps_b.device
+    fs, k1 = _cov_struct(f, Dx, H, Dx, "f")
+    gs, k2 = _cov_struct(g, Dx, H, Dy, "g")
+    qs, k3 = _cov_struct(q1_inv, Dx, H, Dx, "q1_inv")
+    _chk(dscore, (B, N), "dscore")
+    z = lambda *s: _empty(*s, device=dev)
+
+    def zeros(*s):
+        t = _empty(*s, device=dev)
+        if _LAUNCH_STREAM is not None:
+            with torch.cuda.stream(_LAUNCH_STREAM):
+                return t.zero_()
+        return t.zero_()
+    out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dFts": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M),
+           "dGts": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N), "dmu1s": z(T, B, Dx, N),
+           # accumulated with float atomics by the kernel
+           "dFm": zeros(T, B, Dx, N), "dFs": zeros(T, B, Dx, N), "dlogW": zeros(T, B, N), "dlse": zeros(T, B),
+           "dbmu2": zeros(T, B, Dx), "dbsig2": zeros(T, B, Dx), "dminit": zeros(B, Dx), "dsinit": zeros(B, Dx),
+           "dimean": zeros(B, Dx), "disig": zeros(B, Dx), "dsigc_f": zeros(Dx), "dsigc_g": zeros(Dy),
+           "dsigc_q1inv": zeros(Dx)}
+    _mark("psvo_bsim_backward_cov", 0)
+    st = lib.psvo_bsim_backward_cov(
+        ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["Fs"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
+        ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs), _ptr(sigc_f), _ptr(sigc_g), _ptr(sigc_q1inv),
+        _ptr(bmu2), _ptr(bsig2), _ptr(minit), _ptr(sinit), _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b),
+        _ptr(bs["bwX"]), _ptr(bs["sel"]), _ptr(bs["lam"]), _ptr(bs["om"]), _ptr(bs["mu1"]), _ptr(bs["s1"]), _ptr(dscore),
+        _ptr(out["xt"]), _ptr(out["dFt"]), _ptr(out["dFts"]), _ptr(out["dGt"]), _ptr(out["dGts"]), _ptr(out["dmu1"]),
+        _ptr(out["dmu1s"]), _ptr(out["dFm"]), _ptr(out["dFs"]), _ptr(out["dlogW"]), _ptr(out["dlse"]), _ptr(out["dbmu2"]),
+        _ptr(out["dbsig2"]), _ptr(out["dminit"]), _ptr(out["dsinit"]), _ptr(out["dimean"]), _ptr(out["disig"]),
+        _ptr(out["dsigc_f"]), _ptr(out["dsigc_g"]), _ptr(out["dsigc_q1inv"]), _stream())
+    _mark("psvo_bsim_backward_cov", 1)
+    _lib.check(st, "psvo_bsim_backward_cov")
+    del k1, k2, k3
+
+    def head_grads(p, X, rows_mu, rows_sig, Dout, axis=2):
+        W1, b1, Wm, bm, Ws, bs_ = p
+        gm = split_mlp_grad(mlp_wgrad(X, rows_mu, (W1, b1, Wm, bm), Dx, H, Dout, axis=axis), Dx, H, Dout)
+        gs_ = split_mlp_grad(mlp_wgrad(X, rows_sig, (W1, b1, Ws, bs_), Dx, H, Dout, axis=axis), Dx, H, Dout)
+        return (gm[0] + gs_[0], gm[1] + gs_[1], gm[2], gm[3], gs_[2], gs_[3])
+    out["gf"] = head_grads(f, out["xt"][:T - 1], out["dFt"][:T - 1], out["dFts"][:T - 1], Dx)
+    out["gg"] = head_grads(g, out["xt"], out["dGt"], out["dGts"], Dy)
+    out["gq1inv"] = head_grads(q1_inv, bs["bwX"][1:], out["dmu1"][:T - 1], out["dmu1s"][:T - 1], Dx)
+    return out
+
+
 def _chain_rows(out, z, T, B, Dx, N):
     """per-chain rows of d bmu2 (T,B,Dx,N), d minit and d imean (B,Dx,N) in ONE buffer, so that one reduction over the
     chains serves all three (they sit on the dependent chain in front of the encoder BPTT)"""

@@ -149,6 +149,37 @@ def test_trainer_improves_elbo(built_lib, tmp_path, monkeypatch, objective, hipg
     assert (len(graphs) == 1 and all(g is not False for g in graphs.values())) if hipgraph == "1" else not graphs
 
 
+@pytest.mark.parametrize("objective,hipgraph", [("PSVO", "1"), ("PSVO", "0"), ("AESMC", "1")])
+def test_trainer_with_state_dependent_scales(built_lib, tmp_path, monkeypatch, objective, hipgraph):
+    """output_cov and diag_cov through the mirrored trainer (flat parameter buffer incl. the sigma_layer heads, Adam, the
+    local step replayed from a hipGraph or issued eagerly): the ELBO goes up and the evaluation chain runs"""
+    monkeypatch.setenv("PSVO_HIPGRAPH", hipgraph)
+    from oracle import psvo_oracle as O
+    from psvo_amd.model import SSM
+    from psvo_amd.trainer import trainer
+    cls = _objective(objective)
+    monkeypatch.chdir(tmp_path)
+    hid, obs = O.fhn_synthetic(12, 30, seed=0)
+    FLAGS = Hh.make_flags(objective, n_particles=16, n_particles_for_BSim_proposal=4, batch_size=4, time=30, epoch=4,
+                          lr=1e-2, MSE_steps=5, saving_num=4, rslt_dir_name="t", output_cov=True, diag_cov=True)
+    torch.manual_seed(0); np.random.seed(0)
+    model = SSM(FLAGS).cuda()
+    smc = cls(model, FLAGS)
+    smc.generator = torch.Generator(device="cuda").manual_seed(1)
+    tr = trainer(model, smc, FLAGS)
+    rlt = str(tmp_path) + "/rslts/t/run/"
+    os.makedirs(rlt)
+    tr.init_data_saving(rlt)
+    heads0 = [tr_.sigma_kernel.detach().clone() for tr_ in (model.q1_tran, model.g_tran)]
+    hist, log = tr.train(obs[:8].numpy(), obs[8:].numpy(), hid[:8].numpy(), hid[8:].numpy(), print_freq=1)
+    assert len(hist["log_ZSMC_trains"]) == 5 and hist["log_ZSMC_trains"][-1] > hist["log_ZSMC_trains"][0] + 1.0
+    assert all(np.isfinite(hist["log_ZSMC_tests"]))
+    for w0, tr_ in zip(heads0, (model.q1_tran, model.g_tran)):       # the heads are trained
+        assert float((tr_.sigma_kernel.detach() - w0).abs().max()) > 1e-4
+    graphs = tr.__dict__.get("_graphs", {})
+    assert (len(graphs) == 1 and all(g is not False for g in graphs.values())) if hipgraph == "1" else not graphs
+
+
 @pytest.mark.parametrize("obj,layers", [("PSVO", "32"), ("SVO", "32"), ("PSVO", "32,32"), ("SVO", "64,64")])
 def test_flat_buffer_gradients_match_autograd_path(built_lib, obj, layers):
     """with optim.FlatParams the native backward passes accumulate straight into the flat gradient buffer

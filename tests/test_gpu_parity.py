@@ -475,6 +475,17 @@ COV_CASES = [
     (("SVO", 2, 6, 24, 1, 2, 2, 32, True, True), dict(_COV, q1_layers="24", g_layers="16", q0_layers="20", q2_layers="50")),
     (("AESMC", 2, 6, 16, 1, 2, 1, 32, True, True), dict(_COV, poisson_emission=True)),
     (("SVO", 2, 5, 40, 1, 3, 2, 16, False, True), dict(_COV, poisson_emission=True)),
+    # the backward simulation on per-particle transition scales (psvo_bsim_forward_cov / _backward_cov)
+    (("PSVO", 2, 6, 8, 4, 2, 1, 16, True, True), _COV),
+    (("PSVO", 2, 7, 64, 16, 2, 1, 32, True, True), _COV),
+    (("PSVO", 2, 6, 50, 8, 3, 1, 32, True, True), _COV),
+    (("PSVO", 1, 5, 36, 32, 4, 2, 32, False, True), _COV),
+    (("PSVO", 2, 5, 130, 16, 2, 1, 64, True, False), _COV),
+    (("PSVO", 1, 5, 20, 4, 3, 1, 32, False, False), _COV),
+    (("PSVO", 2, 6, 16, 8, 2, 1, 32, True, True), dict(_COV, poisson_emission=True)),
+    (("PSVO", 2, 6, 16, 8, 2, 1, 32, False, True), dict(_COV, q1_layers="24", f_layers="40", g_layers="16", q0_layers="20",
+                                                        q2_layers="50")),
+    (("PSVO", 2, 6, 16, 8, 2, 1, 32, True, True), dict(_COV, BSim_use_single_RNN=True, y_smoother_Dhs="8,16")),
 ]
 
 
@@ -486,8 +497,8 @@ def test_state_dependent_scales(built_lib, case, extra):
 
 
 def test_state_dependent_scales_refusals(built_lib):
-    """what is NOT built says so: the backward-simulation objectives with output_cov, and two hidden layers with output_cov"""
-    FLAGS, model, smc, obs, noise = _setup("PSVO", 2, 5, 8, 4, 2, 1, 32, True, True, **_COV)
+    """what is NOT built says so: the backward simulation WITH RESAMPLING with output_cov, and two hidden layers with output_cov"""
+    FLAGS, model, smc, obs, noise = _setup("PSVOwR", 2, 5, 8, 4, 2, 1, 32, True, True, **_COV)
     with pytest.raises(NotImplementedError):
         smc.get_log_ZSMC(obs.float().cuda(), None, noise=Hh.noise_to_hip(noise, "cuda"))
     FLAGS, model, smc, obs, noise = _setup("AESMC", 2, 5, 8, 1, 2, 1, 32, True, True, **dict(_COV, q1_layers="32,32",
