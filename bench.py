@@ -41,21 +41,30 @@ WORKLOADS = {
     # is "64,64", src/runner_flag.py:50-57); optional 10th entry = hidden layers.  Not headline lines.
     "C*-2x32": ("PSVO", 32, 200, 128, 2, 1, 16, 32, 32, 2),
     "C*-2x64": ("PSVO", 32, 200, 128, 2, 1, 16, 64, 32, 2),
+    # C* sizes with state-dependent diagonal scales (FLAGS.output_cov and FLAGS.diag_cov, src/runner_flag.py:67-70): every MLP
+    # with its sigma_layer head, psvo_*_cov kernels; optional 11th entry = covariance heads.  Not a headline line.
+    "C*-cov": ("PSVO", 32, 200, 128, 2, 1, 16, 32, 32, 1, True),
+    "C2-cov": ("AESMC", 16, 200, 64, 2, 1, 16, 32, 32, 1, True),
 }
 FP32_PEAK_TFLOPS = 157.3     # MI355X f32 vector peak == f32-input MFMA dense peak (MI355X_MICROARCH.md)
 EXP_PEAK = 9.8e12            # transcendental quarter rate, exp/s
 
 
-def flop_model(Dx, Dy, N, M, H, E, layers=1):
+def flop_model(Dx, Dy, N, M, H, E, layers=1, cov=False):
     """Algorithmic flop per particle-step of each native kernel (forward figures: SURVEY.md section 8(d);
     backward figures: DESIGN.md section 5).  FMA = 2 flop, exp/log = 1.  `layers` = 2: an H x H layer more per MLP."""
-    mlp = lambda i, o: 2 * H * (i + o) + (layers - 1) * 2 * H * H
+    mlp = lambda i, o: 2 * H * (i + (2 if cov else 1) * o) + (layers - 1) * 2 * H * H      # (cov: two output heads)
     f_filt = mlp(Dx, Dx) + mlp(Dx, Dy) + mlp(E, Dx) / N + 20 * Dx + 6 * Dy + 10
     f_bsim = 2 * mlp(Dx, Dx) + M * (mlp(Dx, Dx) + mlp(Dx, Dy)) + M * N * (3 * Dx + 4) + M * (14 * Dx + 6 * Dy + 12)
     # reverse passes: MLP forward recompute + input-gradient pass (2x), second pair pass (5 Dx + 6 per pair)
     f_filt_b = 2 * (mlp(Dx, Dx) + mlp(Dx, Dy)) + 40 * Dx + 12 * Dy + 20
     f_bsim_b = 2 * mlp(Dx, Dx) + 2 * M * (mlp(Dx, Dx) + mlp(Dx, Dy)) + M * N * (5 * Dx + 6) + M * (20 * Dx + 8 * Dy + 20)
     # the PSVOwR kernels do the same per-item arithmetic as the PSVO ones (plus an O(N) cross-chain draw per step)
+    if cov:     # per-particle scales: one fma per pair and dimension more forward, 2 Dx + 1 per-j sums instead of Dx + 1 in reverse
+        f_bsim += M * N * 2 * Dx
+        f_bsim_b += M * N * 4 * Dx
+        return {"psvo_filter_forward_cov": f_filt, "psvo_bsim_forward_cov": f_bsim,
+                "psvo_filter_backward_cov": f_filt_b, "psvo_bsim_backward_cov": f_bsim_b}, M * N
     return {"psvo_filter_forward": f_filt, "psvo_bsim_forward": f_bsim,
             "psvo_filter_backward": f_filt_b, "psvo_bsim_backward": f_bsim_b,
             "psvo_bsimwr_forward": f_bsim, "psvo_bsimwr_backward": f_bsim_b}, M * N
@@ -96,9 +105,10 @@ def build_objective(wl, device, seed=0):
     flags[obj] = True
     hs = str(H)
     hp = ",".join([hs] * (wl[9] if len(wl) > 9 else 1))        # per-particle MLPs (hoisted q0 / q2 keep one layer)
+    cov = bool(wl[10]) if len(wl) > 10 else False
     FLAGS = Flags(Dx=Dx, Dy=Dy, n_particles=N, n_particles_for_BSim_proposal=M, batch_size=B, time=T,
                   q0_layers=hs, q1_layers=hp, q2_layers=hs, f_layers=hp, g_layers=hp,
-                  y_smoother_Dhs=str(Dh), X0_smoother_Dhs=str(Dh), **flags)
+                  y_smoother_Dhs=str(Dh), X0_smoother_Dhs=str(Dh), output_cov=cov, diag_cov=cov, **flags)
     torch.manual_seed(seed)
     model = SSM(FLAGS).to(device)
     smc = {"PSVO": PSVO, "SVO": SVO, "AESMC": AESMC, "IWAE": IWAE, "PSVOwR": PSVOwR}[obj](model, FLAGS)
@@ -486,7 +496,7 @@ def main():
                 else:
                     calls.append((name, round(t0c.elapsed_time(open_[name]), 3), round(t0c.elapsed_time(e), 3)))
             print("calls:", calls, file=sys.stderr)
-        flops, x_bsim = flop_model(Dx, Dy, N, M, H, Dy, layers)
+        flops, x_bsim = flop_model(Dx, Dy, N, M, H, Dy, layers, cov=len(wl) > 10 and bool(wl[10]))
         cand = {k: v for k, v in kms.items() if k in flops}
         dominant = max(cand, key=lambda k: cand[k][0])
         k_avg = cand[dominant][0] / max(1.0, cand[dominant][1])
@@ -500,7 +510,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "r03_hbm_traffic_Cstar.json")
         if args.workload == "C*" and os.path.exists(tp):
             key = {"psvo_bsim_backward": "bsim_bwd", "psvo_bsim_forward": "bsim_fwd_kernel",
-                   "psvo_filter_backward": "filter_bwd_kernel", "psvo_filter_forward": "filter_fwd"}[dominant]
+                   "psvo_filter_backward": "filter_bwd_kernel", "psvo_filter_forward": "filter_fwd"}.get(dominant, dominant)
             for k, v in json.load(open(tp))["kernels"].items():
                 if key in k and "finalize" not in k and v["hbm_MB_per_launch"] * 1e6 > (traffic or 0.0):
                     traffic, traffic_src = v["hbm_MB_per_launch"] * 1e6, "profiles/r03_hbm_traffic_Cstar.json"

@@ -375,13 +375,14 @@ __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
     using TL = Tile<DX>;
     constexpr int TS = TL::TS;
     constexpr int NJ = 2 * DX + 1;            // per-j sums: d F (DX), d sigma (DX), d W^
+    constexpr int NI = DX + 2;                // floats per item of the pair phase
     constexpr bool kRolled = true;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int NTB = blockDim.x;
     const int B = a.B, T = a.T, N = a.N;
-    const int NP = (N + 7) & ~7;
+    const int NP = (N + 15) & ~15;               // tile padded (W' = -inf: zero weight) to whole tiles of 16
     const int b = blockIdx.y;
     const int cpb = NTB / M;
     const int cl = tid / M, m = tid % M;
@@ -395,7 +396,8 @@ __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
     float* wqi = wg + MG::kSize;
     float* tile = wqi + MQ::kSize;            // [NP][TS]   tile of forward step t - 1
     float* jacc = tile + NP * TS;             // [NJ][NP]   per-j sums of the step over the workgroup
-    float* cacc = jacc + NJ * NP;             // [4 * DX]   per-step sums over the workgroup's chains: d bmu2, d bsig2 | t = T-1: d minit, d sinit | t = 0: d imean, d isig
+    float* xch = jacc + NJ * NP;              // [4][64][NI] items of each wave: x~ (DX), lam2, d lam
+    float* cacc = xch + 4 * 64 * NI;             // [4 * DX]   per-step sums over the workgroup's chains: d bmu2, d bsig2 | t = T-1: d minit, d sinit | t = 0: d imean, d isig
 
     MQ::load(wf, a.f, tid, NTB);
     MG::load(wg, a.g, tid, NTB);
@@ -556,37 +558,91 @@ __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
         }
         // ---- filter term ---------------------------------------------------------------------------------------------------------
         if (!tzero) {
+            // Pair phase with j ON THE LANES of a 16-lane row: lane = (g, j16), row g = lane >> 4 works on the 16 items
+            // (chain, m) that the lanes of its own row own, against forward particle j = 16 jt + j16 of tile jt.  The items
+            // travel through wave-private LDS into registers once per step; per-ITEM sums (d x~) accumulate in registers over
+            // the tiles and are reduced over the row's 16 lanes once per step (four DPP rotations per value); per-j sums
+            // accumulate in registers over the row's items and are reduced over the four rows once per tile (two swap-adds).
+            // (The first version kept lane = item and reduced 2 Dx + 1 per-j values over the wave for EVERY j: 15.8 ms at C*.)
             const float lam2 = a.lam_all[(tb * N + n) * M + m];
-            const float dl = valid ? dlam : 0.f;
-            float xr[DX];
+            float* const xw = xch + (tid >> 6) * 64 * NI;
+            {
 #pragma unroll
-            for (int d = 0; d < DX; ++d) xr[d] = x[d];
-            for (int j = 0; j < N; ++j) {
+                for (int d = 0; d < DX; ++d) xw[lane * NI + d] = x[d];
+                xw[lane * NI + DX] = lam2;
+                xw[lane * NI + DX + 1] = valid ? dlam : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int g16 = lane & ~15, j16 = lane & 15;
+            float ix[16][DX], il[16], idl[16], ixa[16][DX];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    ix[i][d] = xw[(g16 + i) * NI + d];
+                    ixa[i][d] = 0.f;
+                }
+                il[i] = xw[(g16 + i) * NI + DX];
+                idl[i] = xw[(g16 + i) * NI + DX + 1];
+            }
+            for (int jt = 0; jt < NP; jt += 16) {
+                const int j = jt + j16;
                 const float* p = tile + j * TS;
-                float acc = p[2 * DX], u[DX];
+                float Fp[DX], Rp[DX], Rk[DX];
 #pragma unroll
                 for (int d = 0; d < DX; ++d) {
-                    u[d] = fmaf(xr[d], p[DX + d], -p[d]);     // (x - F_j) kappa / sigma_j
-                    acc = fmaf(-u[d], u[d], acc);
+                    Fp[d] = p[d];
+                    Rp[d] = p[DX + d];
+                    Rk[d] = Rp[d] * (1.f / kap);          // 1 / sigma_jd
                 }
-                const float cj = dl * exp2_fast(acc - lam2);   // d lam_m * p_mj
-                float vals[NJ];
+                const float Wp = p[2 * DX];
+                float ja[NJ];
 #pragma unroll
-                for (int d = 0; d < DX; ++d) {
-                    const float zr = u[d] * p[DX + d];           // (x - F) kappa^2 / sigma^2 = (x - F) / sigma^2 * (log2e / 2)
-                    const float g1 = cj * zr * (2.f * kLn2);     // c (x - F) / sigma^2
-                    dx[d] -= g1;
-                    vals[d] = g1;                                // d F_jd
-                    const float z2 = u[d] * u[d] * (2.f * kLn2);   // ((x - F) / sigma)^2
-                    vals[DX + d] = cj * (z2 - 1.f) * (p[DX + d] * (1.f / kap));   // d sigma_jd = c (z^2 - 1) / sigma
+                for (int q = 0; q < NJ; ++q) ja[q] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float acc = Wp, u[DX];
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) {
+                        u[d] = fmaf(ix[i][d], Rp[d], -Fp[d]);       // (x - F_j) kappa / sigma_j
+                        acc = fmaf(-u[d], u[d], acc);
+                    }
+                    const float cj = idl[i] * exp2_fast(acc - il[i]);   // d lam_k * p_kj
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) {
+                        const float g1 = cj * (u[d] * Rp[d]) * (2.f * kLn2);          // c (x - F) / sigma^2
+                        ixa[i][d] += g1;
+                        ja[d] += g1;                                                  // d F_jd
+                        ja[DX + d] += cj * fmaf(u[d] * u[d], 2.f * kLn2, -1.f) * Rk[d];   // d sigma_jd = c (z^2 - 1) / sigma
+                    }
+                    ja[2 * DX] += cj;                                                 // d W^_j
                 }
-                vals[2 * DX] = cj;                               // d W^_j
 #pragma unroll
                 for (int q = 0; q < NJ; ++q) {
-                    const float s = wave_sum(vals[q]);
-                    if (lane == 0) atomicAdd(&jacc[q * NP + j], s);
+                    float v = ja[q];
+                    v += xor_lane<16>(v);
+                    v += xor_lane<32>(v);
+                    if (lane < 16) atomicAdd(&jacc[q * NP + j], v);
                 }
             }
+            // item sums over the row's 16 lanes; item i of the row is owned by the row's lane i, which keeps the sum
+            float mine[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) mine[d] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) {
+                    float v = ixa[i][d];
+                    v += dpp_mov<0x128, 0xF, 0xF, true>(v, v);   // row_ror:8
+                    v += dpp_mov<0x124, 0xF, 0xF, true>(v, v);   // row_ror:4
+                    v += dpp_mov<0x122, 0xF, 0xF, true>(v, v);   // row_ror:2
+                    v += dpp_mov<0x121, 0xF, 0xF, true>(v, v);   // row_ror:1
+                    mine[d] = (j16 == i) ? v : mine[d];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d) dx[d] -= mine[d];
         } else {
             float dmi = 0.f, dsi = 0.f;
 #pragma unroll
@@ -713,11 +769,12 @@ template <int DX, int DY, int H, int M>
 static int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     using MQ = MlpLds<DX, H, 2 * DX, 1>;
     using MG = MlpLds<DX, H, 2 * DY, 1>;
-    const int NP = (a.N + 7) & ~7;
+    const int NP = (a.N + 15) & ~15;
     int NTB = ((a.N * M + 63) / 64) * 64;
     if (NTB > 256) NTB = 256;
     const int cpb = NTB / M;
-    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + (size_t)NP * (Tile<DX>::TS + 2 * DX + 1) + 4 * DX + 16);
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + (size_t)NP * (Tile<DX>::TS + 2 * DX + 1) +
+                                        4 * 64 * (DX + 2) + 4 * DX + 16);
     dim3 grid((a.N + cpb - 1) / cpb, a.B);
     clear_hip_error();
     hipLaunchKernelGGL((bsim_cov_bwd_kernel<DX, DY, H, M>), grid, dim3(NTB), lds, stream, a);
