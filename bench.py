@@ -45,6 +45,7 @@ WORKLOADS = {
     # with its sigma_layer head, psvo_*_cov kernels; optional 11th entry = covariance heads.  Not a headline line.
     "C*-cov": ("PSVO", 32, 200, 128, 2, 1, 16, 32, 32, 1, True),
     "C2-cov": ("AESMC", 16, 200, 64, 2, 1, 16, 32, 32, 1, True),
+    "C*wR-cov": ("PSVOwR", 32, 200, 128, 2, 1, 16, 32, 32, 1, True),
 }
 FP32_PEAK_TFLOPS = 157.3     # MI355X f32 vector peak == f32-input MFMA dense peak (MI355X_MICROARCH.md)
 EXP_PEAK = 9.8e12            # transcendental quarter rate, exp/s
@@ -64,7 +65,8 @@ def flop_model(Dx, Dy, N, M, H, E, layers=1, cov=False):
         f_bsim += M * N * 2 * Dx
         f_bsim_b += M * N * 4 * Dx
         return {"psvo_filter_forward_cov": f_filt, "psvo_bsim_forward_cov": f_bsim,
-                "psvo_filter_backward_cov": f_filt_b, "psvo_bsim_backward_cov": f_bsim_b}, M * N
+                "psvo_filter_backward_cov": f_filt_b, "psvo_bsim_backward_cov": f_bsim_b,
+                "psvo_bsimwr_forward_cov": f_bsim, "psvo_bsimwr_backward_cov": f_bsim_b}, M * N
     return {"psvo_filter_forward": f_filt, "psvo_bsim_forward": f_bsim,
             "psvo_filter_backward": f_filt_b, "psvo_bsim_backward": f_bsim_b,
             "psvo_bsimwr_forward": f_bsim, "psvo_bsimwr_backward": f_bsim_b}, M * N

@@ -250,6 +250,47 @@ int psvo_bsim_backward_cov(const psvo_desc* desc,
                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * PSVOwR (backward simulation WITH RESAMPLING across the chains, reference src/SMC/PSVOwR.py:65-198) with state-dependent
+ * diagonal scales.  Inputs as psvo_bsim_forward_cov plus u_r (T,B,N) uniforms of the cross-chain draw (or anc_in (T,B,N)
+ * teacher-forced ancestors); outputs as psvo_bsimwr_forward: bwX, bwXanc (T,B,Dx,N), bwW (T,B,N) per-step chain
+ * log-weights, lseW (T,B) = logsumexp_n bwW, sel_out, anc_out (T,B,N), plus omsel (T,B,N) (the drawn sub-particles'
+ * normalised log-weights = the logits of the cross-chain draw; required) and the four saves.
+ * The cross-chain draw couples every chain of a sequence once per step: the loop is T + 2 launches (one per time step,
+ * one for the draw of step 0, one for lseW) issued by this call on `stream`; no cooperative launch, no workspace.
+ * psvo_bsimwr_backward_cov: its reverse (T launches); outputs as psvo_bsim_backward_cov (rows; accumulated with float
+ * atomics into zero-filled dFm, dFs, dlogW, dlse, dbmu2, dbsig2, dminit, dsinit, dimean, disig, dsigc_*); the q1_inv rows
+ * dmu1 / dmu1s pair with the inputs bwXanc[t+1]; dXs (T,B,Dx,N): zero-filled workspace (d loss / d bwX).
+ * ------------------------------------------------------------------------------------------- */
+int psvo_bsimwr_forward_cov(const psvo_desc* desc,
+                            const float* Fm, const float* Fs, const float* logW, const float* lse,
+                            const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
+                            const float* sigc_f, const float* sigc_g, const float* sigc_q1inv,
+                            const float* bmu2, const float* bsig2,
+                            const float* minit, const float* sinit, const float* imean, const float* isig,
+                            const float* obs, const float* eps_b, const float* u_b, const float* u_r,
+                            const int32_t* sel_in, const int32_t* anc_in,
+                            float* bwX, float* bwXanc, float* bwW, float* lseW, int32_t* sel_out, int32_t* anc_out,
+                            float* omsel, float* lam_all, float* om_all, float* mu1_all, float* s1_all,
+                            void* stream);
+int psvo_bsimwr_backward_cov(const psvo_desc* desc,
+                             const float* Fm, const float* Fs, const float* logW, const float* lse,
+                             const psvo_mlp* f, const psvo_mlp* g, const psvo_mlp* q1_inv,
+                             const float* sigc_f, const float* sigc_g, const float* sigc_q1inv,
+                             const float* bmu2, const float* bsig2,
+                             const float* minit, const float* sinit, const float* imean, const float* isig,
+                             const float* obs, const float* eps_b,
+                             const float* bwXanc, const float* bwW, const float* lseW,
+                             const int32_t* sel, const int32_t* anc,
+                             const float* lam_all, const float* om_all, const float* mu1_all, const float* s1_all,
+                             const float* dlseW,
+                             float* xt, float* dFt, float* dFts, float* dGt, float* dGts, float* dmu1, float* dmu1s,
+                             float* dFm, float* dFs, float* dlogW, float* dlse,
+                             float* dbmu2, float* dbsig2,
+                             float* dminit, float* dsinit, float* dimean, float* disig,
+                             float* dsigc_f, float* dsigc_g, float* dsigc_q1inv,
+                             float* dXs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Backward simulation with proposal.  Replaces PSVO.backward_simulation_w_proposal
  * (reference src/SMC/PSVO.py:69-203): the (M, N, N, B) transition tile (:128-133) is never
  * materialised -- forward-particle means are staged in LDS and reduced with an online

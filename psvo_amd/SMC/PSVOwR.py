@@ -21,9 +21,7 @@ class PSVOwR(PSVO):
         batch_size, time, _ = obs.shape
         self.Dx, self.batch_size, self.time = self.model.Dx, batch_size, time
         if self.model.output_cov:
-            raise NotImplementedError("output_cov (state-dependent scales) is built for SVO / AESMC / IWAE / PSVO "
-                                      "(psvo_filter_forward_cov, psvo_bsim_forward_cov); the backward simulation WITH "
-                                      "RESAMPLING has no such kernel and there is no fallback path")
+            return self._get_log_ZSMC_cov(obs, noise)
 
         log = {}
         # (second side stream for the bsim weight gradients only in the default wiring: otherwise the hoisted
@@ -39,6 +37,53 @@ class PSVOwR(PSVO):
         # PSVOwR.py:144-148, 184-185: log_ZSMC = sum_t [logsumexp_n bw_log_W_t - log N], averaged over the batch
         log_ZSMC = (bs["lseW"].sum(0) - time * math.log(float(self.n_particles))).mean()
         log["Xs"] = bs["bwXanc"].permute(1, 0, 3, 2)                   # (B, T, N, Dx), PSVOwR.py:198
+        log["filter"], log["bsim"] = filt, bs
+        self._release()
+        return log_ZSMC, log
+
+    def _get_log_ZSMC_cov(self, obs, noise):
+        """get_log_ZSMC with state-dependent diagonal scales (FLAGS.output_cov and FLAGS.diag_cov): psvo_filter_forward_cov,
+        then psvo_bsimwr_forward_cov (one launch per time step: the kernel boundary is the cross-chain exchange); one stream."""
+        from ..autograd import BsimWRCovFunction
+        model = self.model
+        noise = noise or {}
+        log = {}
+        self._release()
+        self._ov = None
+        self._sigmas = model.sigmas()
+        filt = self.SMC(None, obs, noise=noise)
+        Dx, T, N, B = self.Dx, self.time, self.n_particles, self.batch_size
+        M = self.n_particles_for_BSim_proposal
+        dev = obs.device
+        _, preprocessed_obs = self.BS_preprocess_obs(obs)
+        bmu2, bsig2 = (v.transpose(0, 1).contiguous()
+                       for v in self.BSim_q2.mean_and_sigma(preprocessed_obs, self._sigma(self.BSim_q2)))
+        minit, sinit = self.BSim_q_init.mean_and_sigma(preprocessed_obs[:, -1], self._sigma(self.BSim_q_init))
+        mu_0 = self.preprocessed_X0
+        if not (model.use_bootstrap and model.use_2_q):
+            imean, isig = self.f.mean_and_sigma(mu_0, self._sigma(self.f))       # PSVOwR.py:167
+        else:
+            imean, isig = self._m0, self._sig0                                   # PSVOwR.py:169
+        eps_b = noise.get("eps_b")
+        if eps_b is None:
+            eps_b = self._randn(T, B, Dx, N, M, device=dev)
+        u_b, sel_in = noise.get("u_b"), noise.get("sel_b")
+        if u_b is None and sel_in is None:
+            u_b = self._rand(T, B, N, device=dev)
+        u_r, anc_in = noise.get("u_r"), noise.get("anc_r")
+        if u_r is None and anc_in is None:
+            u_r = self._rand(T, B, N, device=dev)
+        obs_TB = getattr(self, "_obs_TB", None)
+        if obs_TB is None or obs_TB.shape[:2] != (T, B):
+            obs_TB = obs.transpose(0, 1).contiguous().float()
+        lseW, bwXanc, bwX, bwW, sel, anc = BsimWRCovFunction.apply(
+            self._desc(M), obs_TB, eps_b, u_b, u_r, sel_in, anc_in, filt["Fm"], filt["Fs"], filt["logW"], filt["lse"],
+            *self._mlp_params_cov(model.f_tran), *self._mlp_params_cov(model.g_tran), *self._mlp_params_cov(model.q1_inv_tran),
+            self._sigma(self.f), self._sigma(self.g), self._sigma(self.q1_inv),
+            bmu2, bsig2, minit, sinit.expand(B, Dx), imean, isig.expand(B, Dx))
+        bs = {"lseW": lseW, "bwXanc": bwXanc, "bwX": bwX, "bwW": bwW, "sel": sel, "anc": anc}
+        log_ZSMC = (lseW.sum(0) - T * math.log(float(N))).mean()               # PSVOwR.py:144-148, 184-185
+        log["Xs"] = bwXanc.permute(1, 0, 3, 2)
         log["filter"], log["bsim"] = filt, bs
         self._release()
         return log_ZSMC, log

@@ -50,6 +50,8 @@ SIGNATURES = {
     "psvo_filter_backward_cov": (ctypes.c_int, [_DESC, _MLP, _MLP, _MLP] + [_P] * 39 + [_P]),
     "psvo_bsim_forward_cov": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 23 + [_P]),
     "psvo_bsim_backward_cov": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 38 + [_P]),
+    "psvo_bsimwr_forward_cov": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 26 + [_P]),
+    "psvo_bsimwr_backward_cov": (ctypes.c_int, [_DESC] + [_P] * 4 + [_MLP, _MLP, _MLP] + [_P] * 42 + [_P]),
     "psvo_mlp_wgrad_blocks": (ctypes.c_int, [ctypes.c_longlong]),
     "psvo_mlp_wgrad": (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       _P, _P, _MLP, _P, _P, ctypes.c_int, _P]),

@@ -437,6 +437,39 @@ class BsimCovFunction(torch.autograd.Function):
             r["disig"])
 
 
+class BsimWRCovFunction(torch.autograd.Function):
+    """psvo_bsimwr_forward_cov / psvo_bsimwr_backward_cov: PSVOwR with state-dependent diagonal scales.
+
+    apply(desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, Fm, Fs, logW, lse, f (6), g (6), q1_inv (6),
+          sigc_f, sigc_g, sigc_q1inv, bmu2, bsig2, minit, sinit, imean, isig)
+      -> lseW (T,B) [differentiable]; bwXanc, bwX (T,B,Dx,N), bwW (T,B,N), sel, anc (T,B,N) [constants]"""
+
+    @staticmethod
+    def forward(ctx, desc, obs_TB, eps_b, u_b, u_r, sel_in, anc_in, Fm, Fs, logW, lse, *t):
+        t = [_cf(v) for v in t]
+        f, g, q1_inv = tuple(t[0:6]), tuple(t[6:12]), tuple(t[12:18])
+        rest = t[18:27]
+        filt = {"Fm": _cf(Fm), "Fs": _cf(Fs), "logW": _cf(logW), "lse": _cf(lse)}
+        bs = ops.bsimwr_forward_cov(desc, filt, f, g, q1_inv, *rest, obs_TB, eps_b, u_b=u_b, u_r=u_r, sel_in=sel_in,
+                                    anc_in=anc_in, save=any(ctx.needs_input_grad))
+        ctx.desc, ctx.filt, ctx.bs = desc, filt, _aliases(bs)
+        ctx.saved = (f, g, q1_inv, rest, obs_TB, eps_b)
+        ctx.mark_non_differentiable(bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"])
+        ctx.set_materialize_grads(False)
+        return bs["lseW"], bs["bwXanc"], bs["bwX"], bs["bwW"], bs["sel"], bs["anc"]
+
+    @staticmethod
+    def backward(ctx, dlseW, *_):
+        desc = ctx.desc
+        if dlseW is None:
+            dlseW = torch.zeros(desc.T, desc.B, device=ctx.filt["Fm"].device)
+        f, g, q1_inv, rest, obs_TB, eps_b = ctx.saved
+        r = ops.bsimwr_backward_cov(desc, ctx.filt, f, g, q1_inv, *rest, obs_TB, eps_b, ctx.bs, _cg(dlseW).float())
+        return (None,) * 7 + (r["dFm"], r["dFs"], r["dlogW"], r["dlse"]) + r["gf"] + r["gg"] + r["gq1inv"] + (
+            r["dsigc_f"], r["dsigc_g"], r["dsigc_q1inv"], r["dbmu2"], r["dbsig2"], r["dminit"], r["dsinit"], r["dimean"],
+            r["disig"])
+
+
 def _note_exchange(desc, ws, bit):
     """OR the launch's exchange-timeout flag (last word of its workspace, cleared by every launch) into the sticky
     device word the objective keeps across launches (PSVOwR.check_exchange reads it): bit 1 = forward, bit 2 = reverse."""

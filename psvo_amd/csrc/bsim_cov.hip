@@ -43,6 +43,12 @@ struct FwdArgs {
     int32_t* sel_out;
     float* score;
     float *lam_all, *om_all, *mu1_all, *s1_all;
+    // PSVOwR (WR = true): one launch per time step, t_hi == t_lo (or -1: only the cross-chain draw of step 0)
+    int t_hi, t_lo;
+    const float* u_r;          // (T,B,N) uniforms of the cross-chain draw
+    const int32_t* anc_in;     // (T,B,N) teacher-forced ancestors or null
+    float *bwXanc, *bwW, *omsel;   // (T,B,Dx,N), (T,B,N), (T,B,N): resampled chain states, per-step log-weights, drawn omegas
+    int32_t* anc_out;          // (T,B,N)
 };
 
 // forward tile of one filter step in LDS: slot j = [F'_0.. | R'_0.. | W' | pad], TS floats
@@ -65,7 +71,13 @@ struct Tile {
     }
 };
 
-template <int DX, int DY, int H, int M>
+// WR = false: PSVO, persistent over t = T-1 .. 0.  WR = true: PSVOwR (src/SMC/PSVOwR.py:65-198) -- the chains of a sequence
+// are resampled ACROSS the particle axis after every step (logits = the drawn sub-particles' normalised log-weights,
+// PSVOwR.py:103,145,185), which couples all workgroups of a sequence once per step: the loop then runs one launch per time
+// step (host loop in psvo_bsimwr_forward_cov, captured into the step's hipGraph like any other launch), and the cross-chain
+// draw of step t+1 is made at the START of the launch of step t, by every workgroup for its own chains, from the N logits
+// the previous launch left in HBM -- the kernel boundary is the exchange.
+template <int DX, int DY, int H, int M, bool WR>
 __global__ void __launch_bounds__(256) bsim_cov_fwd_kernel(const FwdArgs a) {
     using MQ = MlpLds<DX, H, 2 * DX, 1>;
     using MG = MlpLds<DX, H, 2 * DY, 1>;
@@ -91,6 +103,8 @@ __global__ void __launch_bounds__(256) bsim_cov_fwd_kernel(const FwdArgs a) {
     float* wg = wf + MQ::kSize;
     float* wqi = wg + MG::kSize;
     float* tile = wqi + MQ::kSize;   // [2][NP][TS]
+    float* cdf = tile + 2 * NP * TS; // WR: [1024 + 32] CDF of the cross-chain draw + scratch
+    const int t_hi = WR ? a.t_hi : T - 1, t_lo = WR ? a.t_lo : 0;
 
     MQ::load(wf, a.f, tid, NTB);
     MG::load(wg, a.g, tid, NTB);
@@ -104,6 +118,69 @@ __global__ void __launch_bounds__(256) bsim_cov_fwd_kernel(const FwdArgs a) {
     }
 #pragma unroll
     for (int e = 0; e < DY; ++e) cg[e] = a.sc_g[e];
+    float xp[DX];   // x_{t+1} of this chain (same in all M lanes)
+#pragma unroll
+    for (int d = 0; d < DX; ++d) xp[d] = 0.f;
+    if constexpr (WR) {
+        // ---- cross-chain draw of step tr = t_hi + 1 (PSVOwR.py:103,145,185): ancestors of this workgroup's chains ----------
+        const int tr = t_hi + 1;
+        if (tr <= T - 1) {
+            const size_t rb = (size_t)tr * B + b;
+            float* red = cdf + 1024;
+            int anc;
+            if (a.anc_in) {
+                anc = a.anc_in[rb * N + n];
+            } else {
+                // inclusive CDF of exp(omega_sel - max) over the N chains: thread i owns entries [4 i, 4 i + 4)
+                float v[4], mx = -__builtin_huge_valf();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = 4 * tid + k;
+                    v[k] = j < N ? a.omsel[rb * N + j] : -__builtin_huge_valf();
+                    mx = fmaxf(mx, v[k]);
+                }
+                mx = wave_max(mx);
+                if (lane == 0) red[tid >> 6] = mx;
+                __syncthreads();
+                mx = red[0];
+                for (int w = 1; w < (NTB >> 6); ++w) mx = fmaxf(mx, red[w]);
+                __syncthreads();
+                float run = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    run += (4 * tid + k < N) ? exp2_fast((v[k] - mx) * kLog2e) : 0.f;
+                    v[k] = run;
+                }
+                const float inc = wave_incl_scan(run, lane);
+                if (lane == 63) red[tid >> 6] = inc;
+                __syncthreads();
+                float off = inc - run, total = 0.f;
+                for (int w = 0; w < (NTB >> 6); ++w) {
+                    if (w < (tid >> 6)) off += red[w];
+                    total += red[w];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * tid + k < 1024) cdf[4 * tid + k] = v[k] + off;
+                __syncthreads();
+                const float target = a.u_r[rb * N + n] * total;
+                int pos = 0;     // count of cdf entries <= target (the filter's search, SVO.py:266-300)
+                for (int st = 1 << (31 - __clz(N)); st > 0; st >>= 1) {
+                    const int q = pos + st;
+                    if (q <= N && cdf[q - 1] <= target) pos = q;
+                }
+                anc = min(pos, N - 1);
+            }
+#pragma unroll
+            for (int d = 0; d < DX; ++d) xp[d] = a.bwX[(rb * DX + d) * N + anc];
+            if (valid && lead) {
+                a.anc_out[rb * N + n] = anc;
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.bwXanc[(rb * DX + d) * N + n] = xp[d];
+            }
+        }
+        if (t_hi < 0) return;      // (the launch behind step 0: only the draw)
+    }
     float mi[DX], si[DX], im[DX], is[DX];
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
@@ -141,8 +218,8 @@ __global__ void __launch_bounds__(256) bsim_cov_fwd_kernel(const FwdArgs a) {
             if (j < NP) TL::put(buf, j, N, st[r], st_l);
         }
     };
-    if (T >= 2) {
-        stage_load(T - 2);
+    if (t_hi >= 1) {
+        stage_load(t_hi - 1);
         stage_store(tile);
     }
 
@@ -161,24 +238,22 @@ __global__ void __launch_bounds__(256) bsim_cov_fwd_kernel(const FwdArgs a) {
         if (a.sel_in) ss = a.sel_in[tb * N + n];
         else uu = a.u_b[tb * N + n];
     };
-    load_inputs(T - 1, eps_c, bmu_c, bs_c, obs_c, u_c, sel_c);
+    load_inputs(t_hi, eps_c, bmu_c, bs_c, obs_c, u_c, sel_c);
     __syncthreads();
 
-    float xp[DX];   // x_{t+1} of this chain (same in all M lanes)
-#pragma unroll
-    for (int d = 0; d < DX; ++d) xp[d] = 0.f;
     float score = 0.f;
 
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t = t_hi; t >= t_lo; --t) {
         const size_t tb = (size_t)t * B + b;
-        const float* cur = tile + ((T - 1 - t) & 1) * NP * TS;
-        float* nxt = tile + ((T - t) & 1) * NP * TS;
+        const float* cur = tile + ((t_hi - t) & 1) * NP * TS;
+        float* nxt = tile + ((t_hi - t + 1) & 1) * NP * TS;
         const bool last = (t == T - 1), tzero = (t == 0);
+        const bool more = (t > t_lo);             // another step follows in this launch
 
         float eps_n[DX], bmu_n[DX], bs_n[DX], obs_n[DY], u_n = 0.f;
         int sel_n = 0;
-        if (!tzero) load_inputs(t - 1, eps_n, bmu_n, bs_n, obs_n, u_n, sel_n);
-        if (t >= 2) stage_load(t - 2);
+        if (more) load_inputs(t - 1, eps_n, bmu_n, bs_n, obs_n, u_n, sel_n);
+        if (more && t >= 2) stage_load(t - 2);
 
         // ---- proposal ---------------------------------------------------------------------------------------------------
         float x[DX], mu[DX], ic[DX];
@@ -314,16 +389,29 @@ __global__ void __launch_bounds__(256) bsim_cov_fwd_kernel(const FwdArgs a) {
         const float om_s = __shfl(omega, src), phi_s = __shfl(phi, src), g_s = __shfl(g_lp, src), q_s = __shfl(q_lp, src),
                     lam_s = __shfl(lam, src);
         const float Om = om_s + q_s + logM;
-        if (valid && lead) {
+        if constexpr (WR) {
+            // per-step log-weight of the chain (PSVOwR.py:97-101, 134-141, 176-181): Lam (t >= 1) or the prior term (t = 0)
+            // + g - (q + omega + log M) of the drawn sub-particle
+            (void)phi_s;
+            if (valid && lead) {
 #pragma unroll
-            for (int d = 0; d < DX; ++d) a.bwX[(tb * DX + d) * N + n] = xs[d];
-            a.glp[tb * N + n] = g_s;
-            a.Omega[tb * N + n] = Om;
-            a.sel_out[tb * N + n] = sel;
-            if (!last) a.flp[(tb + B) * N + n] = phi_s;     // f_log_probs[t+1]
-            if (tzero) a.flp[(size_t)b * N + n] = lam_s;    // f_log_probs[0] = f_init
+                for (int d = 0; d < DX; ++d) a.bwX[(tb * DX + d) * N + n] = xs[d];
+                a.bwW[tb * N + n] = lam_s + g_s - Om;
+                a.omsel[tb * N + n] = om_s;
+                a.sel_out[tb * N + n] = sel;
+            }
+        } else {
+            if (valid && lead) {
+#pragma unroll
+                for (int d = 0; d < DX; ++d) a.bwX[(tb * DX + d) * N + n] = xs[d];
+                a.glp[tb * N + n] = g_s;
+                a.Omega[tb * N + n] = Om;
+                a.sel_out[tb * N + n] = sel;
+                if (!last) a.flp[(tb + B) * N + n] = phi_s;     // f_log_probs[t+1]
+                if (tzero) a.flp[(size_t)b * N + n] = lam_s;    // f_log_probs[0] = f_init
+            }
+            score += g_s - Om + (last ? 0.f : phi_s) + (tzero ? lam_s : 0.f);
         }
-        score += g_s - Om + (last ? 0.f : phi_s) + (tzero ? lam_s : 0.f);
 
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
@@ -336,10 +424,26 @@ __global__ void __launch_bounds__(256) bsim_cov_fwd_kernel(const FwdArgs a) {
         for (int k = 0; k < DY; ++k) obs_c[k] = obs_n[k];
         u_c = u_n;
         sel_c = sel_n;
-        if (t >= 2) stage_store(nxt);
+        if (more && t >= 2) stage_store(nxt);
         __syncthreads();
     }
-    if (valid && lead) a.score[(size_t)b * N + n] = score;
+    if constexpr (!WR) {
+        if (valid && lead) a.score[(size_t)b * N + n] = score;
+    }
+}
+
+// lseW[t][b] = logsumexp_n bwW[t][b][:]  (PSVOwR.py:52-63; one wave per (t, b))
+__global__ void __launch_bounds__(256) wr_lse_kernel(const float* __restrict__ W, long long rows, int N, float* __restrict__ out) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float mx = -__builtin_huge_valf();
+    for (int l = lane; l < N; l += 64) mx = fmaxf(mx, W[r * N + l]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int l = lane; l < N; l += 64) s += exp2_fast((W[r * N + l] - mx) * kLog2e);
+    s = wave_sum(s);
+    if (lane == 0) out[r] = fmaf(kLn2, log2_fast(s), mx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -366,9 +470,19 @@ struct BwdArgs {
     float *dbmu2, *dbsig2;                  // (T,B,Dx)
     float *dminit, *dsinit, *dimean, *disig;   // (B,Dx)
     float *dsc_f, *dsc_g, *dsc_q1inv;       // (Dx), (Dy), (Dx)
+    // PSVOwR (WR = true): one launch per time step t_lo == t_hi
+    int t_lo, t_hi;
+    const float *bwXanc, *bwW, *lseW, *dlseW;   // (T,B,Dx,N), (T,B,N), (T,B), (T,B)
+    const int32_t* anc;                     // (T,B,N)
+    float* dXs;                             // (T,B,Dx,N) d loss / d bwX (zero-filled by the caller; float atomics)
 };
 
-template <int DX, int DY, int H, int M>
+// WR = false: PSVO, persistent over t = 0 .. T-1 with d loss / d bwX[t] carried in registers.  WR = true: PSVOwR, one launch
+// per time step; the loss is sum_t logsumexp_n W_t[n], so with aw = d loss / d W_t[n] = dlseW_t softmax_n(W_t):
+//   W = logsumexp_m(omega_raw) - phi_s - log M   =>   d lam_m = d g_m = -d q_m = aw p_m,   d phi_m = aw (p_m - [m == s]),
+// and the chain's x_{t+1} is the RESAMPLED state bwXanc[t+1][n] = bwX[t+1][anc], so its gradient is scatter-added into the
+// ancestor chain's d bwX[t+1] (HBM float atomics; the next launch reads it).
+template <int DX, int DY, int H, int M, bool WR>
 __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
     using MQ = MlpLds<DX, H, 2 * DX, 1>;
     using MG = MlpLds<DX, H, 2 * DY, 1>;
@@ -419,8 +533,9 @@ __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
         im[d] = a.imean[b * DX + d];
         is[d] = a.isig[b * DX + d];
     }
-    const float aw = valid ? a.dscore[(size_t)b * N + n] : 0.f;
+    float aw = (!WR && valid) ? a.dscore[(size_t)b * N + n] : 0.f;
     const float kap = sqrtf(0.5f * kLog2e);
+    const int t_lo = WR ? a.t_lo : 0, t_hi = WR ? a.t_hi : T - 1;
 
     float acc_f[DX], acc_q[DX], acc_g[DY];    // sums of d sigma over this lane's rows of the f / q1inv / g heads
 #pragma unroll
@@ -432,9 +547,14 @@ __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
     for (int d = 0; d < DX; ++d) dX[d] = 0.f;
     __syncthreads();
 
-    for (int t = 0; t < T; ++t) {
+    for (int t = t_lo; t <= t_hi; ++t) {
         const size_t tb = (size_t)t * B + b;
         const bool last = (t == T - 1), tzero = (t == 0);
+        if constexpr (WR) {
+            aw = valid ? a.dlseW[tb] * exp2_fast((a.bwW[tb * N + n] - a.lseW[tb]) * kLog2e) : 0.f;
+#pragma unroll
+            for (int d = 0; d < DX; ++d) dX[d] = a.dXs[(tb * DX + d) * N + n];
+        }
 
         // ---- stage the tile of forward step t - 1, zero the step's accumulators ---------------------------------------------
         if (!tzero) {
@@ -461,7 +581,7 @@ __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
             eps[d] = a.eps_b[((tb * DX + d) * N + n) * M + m];
-            xp[d] = last ? 0.f : a.bwX[((tb + B) * DX + d) * N + n];
+            xp[d] = last ? 0.f : (WR ? a.bwXanc : a.bwX)[((tb + B) * DX + d) * N + n];
         }
 #pragma unroll
         for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
@@ -488,8 +608,9 @@ __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
             }
             x[d] = fmaf(c[d], eps[d], mu[d]);
         }
-        const float dgp = aw * p_m;                               // d g_m = d phi_m = -d q_m
-        const float dlam = tzero ? dgp : aw * (p_m - dsel);
+        const float dgp = aw * p_m;                               // d g_m = -d q_m (PSVO: = d phi_m)
+        const float dlam = (WR || tzero) ? dgp : aw * (p_m - dsel);
+        const float dphi = WR ? aw * (p_m - dsel) : dgp;
 
         float dx[DX], dxp[DX];      // gradients w.r.t. this sub-particle and (its share of) w.r.t. the chain's x_{t+1}
 #pragma unroll
@@ -535,9 +656,9 @@ __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
                 const float hx = 0.1f * exp2_fast(fo[DX + d] * kLog2e);
                 const float ifs = rcp(cf[d] + (hx + 1e-7f));
                 const float z = (xp[d] - fo[d]) * ifs;
-                dfo[d] = dgp * z * ifs;
+                dfo[d] = dphi * z * ifs;
                 dxp[d] -= dfo[d];
-                const float ds = dgp * (z * z - 1.f) * ifs;
+                const float ds = dphi * (z * z - 1.f) * ifs;
                 dfo[DX + d] = ds * hx;
                 acc_f[d] += valid ? ds : 0.f;
             }
@@ -691,6 +812,13 @@ __global__ void __launch_bounds__(256) bsim_cov_bwd_kernel(const BwdArgs a) {
             MQ::template bwd_input<kRolled>(wqi, xp, dq, dxq);      // (the same in the chain's M lanes)
 #pragma unroll
             for (int d = 0; d < DX; ++d) dX[d] = group_sum<M>(dxp[d]) + dxq[d];
+            if constexpr (WR) {     // x_{t+1} = bwX[t+1][anc]: the gradient goes to the ancestor chain
+                if (lead) {
+                    const int an = a.anc[(tb + B) * N + n];
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) atomicAdd(&a.dXs[((tb + B) * DX + d) * N + an], dX[d]);
+                }
+            }
         } else {
 #pragma unroll
             for (int d = 0; d < DX; ++d) {
@@ -761,7 +889,29 @@ static int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * Tile<DX>::TS);
     dim3 grid((a.N + cpb - 1) / cpb, a.B);
     clear_hip_error();
-    hipLaunchKernelGGL((bsim_cov_fwd_kernel<DX, DY, H, M>), grid, dim3(NTB), lds, stream, a);
+    hipLaunchKernelGGL((bsim_cov_fwd_kernel<DX, DY, H, M, false>), grid, dim3(NTB), lds, stream, a);
+    return launch_status();
+}
+
+// PSVOwR: one launch per time step T-1 .. 0, one more for the cross-chain draw of step 0, then the per-step logsumexp
+template <int DX, int DY, int H, int M>
+static int launch_fwd_wr(const FwdArgs& a0, float* lseW, hipStream_t stream) {
+    using MQ = MlpLds<DX, H, 2 * DX, 1>;
+    using MG = MlpLds<DX, H, 2 * DY, 1>;
+    const int NP = (a0.N + 7) & ~7;
+    int NTB = ((a0.N * M + 63) / 64) * 64;
+    if (NTB > 256) NTB = 256;
+    const int cpb = NTB / M;
+    const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + 2 * (size_t)NP * Tile<DX>::TS + 1024 + 32);
+    dim3 grid((a0.N + cpb - 1) / cpb, a0.B);
+    clear_hip_error();
+    FwdArgs a = a0;
+    for (int t = a0.T - 1; t >= -1; --t) {
+        a.t_hi = a.t_lo = t;
+        hipLaunchKernelGGL((bsim_cov_fwd_kernel<DX, DY, H, M, true>), grid, dim3(NTB), lds, stream, a);
+    }
+    const long long rows = (long long)a0.T * a0.B;
+    hipLaunchKernelGGL(wr_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a0.bwW, rows, a0.N, lseW);
     return launch_status();
 }
 
@@ -777,7 +927,15 @@ static int launch_bwd(const BwdArgs& a, hipStream_t stream) {
                                         4 * 64 * (DX + 2) + 4 * DX + 16);
     dim3 grid((a.N + cpb - 1) / cpb, a.B);
     clear_hip_error();
-    hipLaunchKernelGGL((bsim_cov_bwd_kernel<DX, DY, H, M>), grid, dim3(NTB), lds, stream, a);
+    if (a.t_lo < 0) {       // PSVO: persistent over all steps
+        hipLaunchKernelGGL((bsim_cov_bwd_kernel<DX, DY, H, M, false>), grid, dim3(NTB), lds, stream, a);
+    } else {                // PSVOwR: one launch per time step, 0 .. T-1
+        BwdArgs w = a;
+        for (int t = 0; t < a.T; ++t) {
+            w.t_lo = w.t_hi = t;
+            hipLaunchKernelGGL((bsim_cov_bwd_kernel<DX, DY, H, M, true>), grid, dim3(NTB), lds, stream, w);
+        }
+    }
     return launch_status();
 }
 
@@ -848,6 +1006,8 @@ extern "C" int psvo_bsim_forward_cov(const psvo_desc* desc, const float* Fm, con
     a.obs = obs; a.eps_b = eps_b; a.u_b = u_b; a.sel_in = sel_in;
     a.bwX = bwX; a.flp = flp; a.glp = glp; a.Omega = Omega; a.sel_out = sel_out; a.score = score;
     a.lam_all = lam_all; a.om_all = om_all; a.mu1_all = mu1_all; a.s1_all = s1_all;
+    a.t_hi = desc->T - 1; a.t_lo = 0; a.u_r = nullptr; a.anc_in = nullptr;
+    a.bwXanc = a.bwW = a.omsel = nullptr; a.anc_out = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     PSVO_COVB_DISPATCH(launch_fwd, a, s);
 }
@@ -884,6 +1044,80 @@ extern "C" int psvo_bsim_backward_cov(
     a.dFm = dFm; a.dFs = dFs; a.dlogW = dlogW; a.dlse = dlse; a.dbmu2 = dbmu2; a.dbsig2 = dbsig2;
     a.dminit = dminit; a.dsinit = dsinit; a.dimean = dimean; a.disig = disig;
     a.dsc_f = dsigc_f; a.dsc_g = dsigc_g; a.dsc_q1inv = dsigc_q1inv;
+    a.t_lo = a.t_hi = -1;       // persistent over all steps
+    a.bwXanc = a.bwW = a.lseW = a.dlseW = nullptr; a.anc = nullptr; a.dXs = nullptr;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PSVO_COVB_DISPATCH(launch_bwd, a, s);
+}
+
+/* PSVOwR with state-dependent scales: see include/psvo_hip.h */
+extern "C" int psvo_bsimwr_forward_cov(
+    const psvo_desc* desc, const float* Fm, const float* Fs, const float* logW, const float* lse, const psvo_mlp* f,
+    const psvo_mlp* g, const psvo_mlp* q1_inv, const float* sigc_f, const float* sigc_g, const float* sigc_q1inv,
+    const float* bmu2, const float* bsig2, const float* minit, const float* sinit, const float* imean, const float* isig,
+    const float* obs, const float* eps_b, const float* u_b, const float* u_r, const int32_t* sel_in, const int32_t* anc_in,
+    float* bwX, float* bwXanc, float* bwW, float* lseW, int32_t* sel_out, int32_t* anc_out, float* omsel, float* lam_all,
+    float* om_all, float* mu1_all, float* s1_all, void* stream) {
+    using namespace psvo;
+    using namespace psvo::covb;
+    if (!desc) return PSVO_ERR_INVALID;
+    if (desc->layers > 1 || desc->layers < 0) return PSVO_ERR_UNSUPPORTED;
+    if (!desc_ok(desc)) return PSVO_ERR_INVALID;
+    if (!Fm || !Fs || !logW || !lse || !f || !g || !q1_inv || !sigc_f || !sigc_g || !sigc_q1inv || !bmu2 || !bsig2 || !minit ||
+        !sinit || !imean || !isig || !obs || !eps_b || !bwX || !bwXanc || !bwW || !lseW || !sel_out || !anc_out || !omsel)
+        return PSVO_ERR_INVALID;
+    if ((!u_b && !sel_in) || (!u_r && !anc_in)) return PSVO_ERR_INVALID;
+    if ((mu1_all != nullptr) != (s1_all != nullptr)) return PSVO_ERR_INVALID;
+    if (desc->N > 1024 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
+    FwdArgs a;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N; a.emission = desc->emission;
+    a.f = *f; a.g = *g; a.q1inv = *q1_inv;
+    a.Fm = Fm; a.Fs = Fs; a.logW = logW; a.lse = lse;
+    a.sc_f = sigc_f; a.sc_g = sigc_g; a.sc_q1inv = sigc_q1inv;
+    a.bmu2 = bmu2; a.bsig2 = bsig2; a.minit = minit; a.sinit = sinit; a.imean = imean; a.isig = isig;
+    a.obs = obs; a.eps_b = eps_b; a.u_b = u_b; a.sel_in = sel_in;
+    a.bwX = bwX; a.flp = nullptr; a.glp = nullptr; a.Omega = nullptr; a.sel_out = sel_out; a.score = nullptr;
+    a.lam_all = lam_all; a.om_all = om_all; a.mu1_all = mu1_all; a.s1_all = s1_all;
+    a.t_hi = a.t_lo = 0; a.u_r = u_r; a.anc_in = anc_in;
+    a.bwXanc = bwXanc; a.bwW = bwW; a.omsel = omsel; a.anc_out = anc_out;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PSVO_COVB_DISPATCH(launch_fwd_wr, a, lseW, s);
+}
+
+extern "C" int psvo_bsimwr_backward_cov(
+    const psvo_desc* desc, const float* Fm, const float* Fs, const float* logW, const float* lse, const psvo_mlp* f,
+    const psvo_mlp* g, const psvo_mlp* q1_inv, const float* sigc_f, const float* sigc_g, const float* sigc_q1inv,
+    const float* bmu2, const float* bsig2, const float* minit, const float* sinit, const float* imean, const float* isig,
+    const float* obs, const float* eps_b, const float* bwXanc, const float* bwW, const float* lseW, const int32_t* sel,
+    const int32_t* anc, const float* lam_all, const float* om_all, const float* mu1_all, const float* s1_all,
+    const float* dlseW, float* xt, float* dFt, float* dFts, float* dGt, float* dGts, float* dmu1, float* dmu1s, float* dFm,
+    float* dFs, float* dlogW, float* dlse, float* dbmu2, float* dbsig2, float* dminit, float* dsinit, float* dimean,
+    float* disig, float* dsigc_f, float* dsigc_g, float* dsigc_q1inv, float* dXs, void* stream) {
+    using namespace psvo;
+    using namespace psvo::covb;
+    if (!desc) return PSVO_ERR_INVALID;
+    if (desc->layers > 1 || desc->layers < 0) return PSVO_ERR_UNSUPPORTED;
+    if (!desc_ok(desc)) return PSVO_ERR_INVALID;
+    if (!Fm || !Fs || !logW || !lse || !f || !g || !q1_inv || !sigc_f || !sigc_g || !sigc_q1inv || !bmu2 || !bsig2 || !minit ||
+        !sinit || !imean || !isig || !obs || !eps_b || !bwXanc || !bwW || !lseW || !sel || !anc || !lam_all || !om_all ||
+        !mu1_all || !s1_all || !dlseW || !xt || !dFt || !dFts || !dGt || !dGts || !dmu1 || !dmu1s || !dFm || !dFs || !dlogW ||
+        !dlse || !dbmu2 || !dbsig2 || !dminit || !dsinit || !dimean || !disig || !dsigc_f || !dsigc_g || !dsigc_q1inv || !dXs)
+        return PSVO_ERR_INVALID;
+    if (desc->N > 1024 || desc->B > 65535) return PSVO_ERR_UNSUPPORTED;
+    BwdArgs a;
+    a.B = desc->B; a.T = desc->T; a.N = desc->N; a.emission = desc->emission;
+    a.f = *f; a.g = *g; a.q1inv = *q1_inv;
+    a.Fm = Fm; a.Fs = Fs; a.logW = logW; a.lse = lse;
+    a.sc_f = sigc_f; a.sc_g = sigc_g; a.sc_q1inv = sigc_q1inv;
+    a.bmu2 = bmu2; a.bsig2 = bsig2; a.minit = minit; a.sinit = sinit; a.imean = imean; a.isig = isig;
+    a.obs = obs; a.eps_b = eps_b; a.bwX = nullptr; a.sel = sel;
+    a.lam_all = lam_all; a.om_all = om_all; a.mu1_all = mu1_all; a.s1_all = s1_all; a.dscore = nullptr;
+    a.xt = xt; a.dFt = dFt; a.dFts = dFts; a.dGt = dGt; a.dGts = dGts; a.dmu1 = dmu1; a.dmu1s = dmu1s;
+    a.dFm = dFm; a.dFs = dFs; a.dlogW = dlogW; a.dlse = dlse; a.dbmu2 = dbmu2; a.dbsig2 = dbsig2;
+    a.dminit = dminit; a.dsinit = dsinit; a.dimean = dimean; a.disig = disig;
+    a.dsc_f = dsigc_f; a.dsc_g = dsigc_g; a.dsc_q1inv = dsigc_q1inv;
+    a.t_lo = a.t_hi = 0;        // (>= 0: one launch per time step)
+    a.bwXanc = bwXanc; a.bwW = bwW; a.lseW = lseW; a.dlseW = dlseW; a.anc = anc; a.dXs = dXs;
     hipStream_t s = static_cast<hipStream_t>(stream);
     PSVO_COVB_DISPATCH(launch_bwd, a, s);
 }

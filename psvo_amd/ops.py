@@ -637,6 +637,98 @@ def bsim_backward_cov(desc, filt, f, g, q1_inv, sigc_f, sigc_g, sigc_q1inv, bmu2
     return out
 
 
+def bsimwr_forward_cov(desc, filt, f, g, q1_inv, sigc_f, sigc_g, sigc_q1inv, bmu2, bsig2, minit, sinit, imean, isig,
+                       obs, eps_b, u_b=None, u_r=None, sel_in=None, anc_in=None, save=False):
+    """psvo_bsimwr_forward_cov (PSVOwR, state-dependent scales).  Returns dict(bwX, bwXanc, bwW, lseW, sel, anc, omsel
+    [, lam, om, mu1, s1])."""
+    lib = _lib.load()
+    B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
+    dev = eps_b.device
+    fs, k1 = _cov_struct(f, Dx, H, Dx, "f")
+    gs, k2 = _cov_struct(g, Dx, H, Dy, "g")
+    qs, k3 = _cov_struct(q1_inv, Dx, H, Dx, "q1_inv")
+    _chk(filt["Fm"], (T, B, Dx, N), "Fm"); _chk(filt["Fs"], (T, B, Dx, N), "Fs")
+    _chk(filt["logW"], (T, B, N), "logW"); _chk(filt["lse"], (T, B), "lse")
+    _chk(sigc_f, (Dx,), "sigc_f"); _chk(sigc_g, (Dy,), "sigc_g"); _chk(sigc_q1inv, (Dx,), "sigc_q1inv")
+    _chk(bmu2, (T, B, Dx), "bmu2"); _chk(bsig2, (T, B, Dx), "bsig2")
+    for t, nm in ((minit, "minit"), (sinit, "sinit"), (imean, "imean"), (isig, "isig")):
+        _chk(t, (B, Dx), nm)
+    _chk(obs, (T, B, Dy), "obs"); _chk(eps_b, (T, B, Dx, N, M), "eps_b")
+    _chk(u_b, (T, B, N), "u_b"); _chk(sel_in, (T, B, N), "sel_in", torch.int32)
+    _chk(u_r, (T, B, N), "u_r"); _chk(anc_in, (T, B, N), "anc_in", torch.int32)
+    if (u_b is None and sel_in is None) or (u_r is None and anc_in is None):
+        raise ValueError("PSVOwR needs uniforms (`u_b`, `u_r`) or teacher-forced indices (`sel_in`, `anc_in`)")
+    z = lambda *s: _empty(*s, device=dev)
+    zi = lambda *s: _empty(*s, device=dev, dtype=torch.int32)
+    out = {"bwX": z(T, B, Dx, N), "bwXanc": z(T, B, Dx, N), "bwW": z(T, B, N), "lseW": z(T, B), "sel": zi(T, B, N),
+           "anc": zi(T, B, N), "omsel": z(T, B, N),
+           "lam": z(T, B, N, M) if save else None, "om": z(T, B, N, M) if save else None,
+           "mu1": z(T, B, Dx, N) if save else None, "s1": z(T, B, Dx, N) if save else None}
+    _mark("psvo_bsimwr_forward_cov", 0)
+    st = lib.psvo_bsimwr_forward_cov(
+        ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["Fs"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
+        ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs), _ptr(sigc_f), _ptr(sigc_g), _ptr(sigc_q1inv),
+        _ptr(bmu2), _ptr(bsig2), _ptr(minit), _ptr(sinit), _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b), _ptr(u_b),
+        _ptr(u_r), _ptr(sel_in), _ptr(anc_in), _ptr(out["bwX"]), _ptr(out["bwXanc"]), _ptr(out["bwW"]), _ptr(out["lseW"]),
+        _ptr(out["sel"]), _ptr(out["anc"]), _ptr(out["omsel"]), _ptr(out["lam"]), _ptr(out["om"]), _ptr(out["mu1"]),
+        _ptr(out["s1"]), _stream())
+    _mark("psvo_bsimwr_forward_cov", 1)
+    _lib.check(st, "psvo_bsimwr_forward_cov")
+    del k1, k2, k3
+    return out
+
+
+def bsimwr_backward_cov(desc, filt, f, g, q1_inv, sigc_f, sigc_g, sigc_q1inv, bmu2, bsig2, minit, sinit, imean, isig,
+                        obs, eps_b, bs, dlseW):
+    """psvo_bsimwr_backward_cov + two psvo_mlp_wgrad launches per MLP.  `bs` = the forward call's outputs with its saves."""
+    lib = _lib.load()
+    B, T, N, M, Dx, Dy, H = desc.B, desc.T, desc.N, desc.M, desc.Dx, desc.Dy, desc.H
+    dev = eps_b.device
+    fs, k1 = _cov_struct(f, Dx, H, Dx, "f")
+    gs, k2 = _cov_struct(g, Dx, H, Dy, "g")
+    qs, k3 = _cov_struct(q1_inv, Dx, H, Dx, "q1_inv")
+    _chk(dlseW, (T, B), "dlseW")
+    z = lambda *s: _empty(*s, device=dev)
+
+    def zeros(*s):
+        t = _empty(*s, device=dev)
+        if _LAUNCH_STREAM is not None:
+            with torch.cuda.stream(_LAUNCH_STREAM):
+                return t.zero_()
+        return t.zero_()
+    out = {"xt": z(T, B, Dx, N, M), "dFt": z(T, B, Dx, N, M), "dFts": z(T, B, Dx, N, M), "dGt": z(T, B, Dy, N, M),
+           "dGts": z(T, B, Dy, N, M), "dmu1": z(T, B, Dx, N), "dmu1s": z(T, B, Dx, N),
+           "dFm": zeros(T, B, Dx, N), "dFs": zeros(T, B, Dx, N), "dlogW": zeros(T, B, N), "dlse": zeros(T, B),
+           "dbmu2": zeros(T, B, Dx), "dbsig2": zeros(T, B, Dx), "dminit": zeros(B, Dx), "dsinit": zeros(B, Dx),
+           "dimean": zeros(B, Dx), "disig": zeros(B, Dx), "dsigc_f": zeros(Dx), "dsigc_g": zeros(Dy),
+           "dsigc_q1inv": zeros(Dx)}
+    dXs = zeros(T, B, Dx, N)
+    _mark("psvo_bsimwr_backward_cov", 0)
+    st = lib.psvo_bsimwr_backward_cov(
+        ctypes.byref(desc), _ptr(filt["Fm"]), _ptr(filt["Fs"]), _ptr(filt["logW"]), _ptr(filt["lse"]),
+        ctypes.byref(fs), ctypes.byref(gs), ctypes.byref(qs), _ptr(sigc_f), _ptr(sigc_g), _ptr(sigc_q1inv),
+        _ptr(bmu2), _ptr(bsig2), _ptr(minit), _ptr(sinit), _ptr(imean), _ptr(isig), _ptr(obs), _ptr(eps_b),
+        _ptr(bs["bwXanc"]), _ptr(bs["bwW"]), _ptr(bs["lseW"]), _ptr(bs["sel"]), _ptr(bs["anc"]), _ptr(bs["lam"]),
+        _ptr(bs["om"]), _ptr(bs["mu1"]), _ptr(bs["s1"]), _ptr(dlseW),
+        _ptr(out["xt"]), _ptr(out["dFt"]), _ptr(out["dFts"]), _ptr(out["dGt"]), _ptr(out["dGts"]), _ptr(out["dmu1"]),
+        _ptr(out["dmu1s"]), _ptr(out["dFm"]), _ptr(out["dFs"]), _ptr(out["dlogW"]), _ptr(out["dlse"]), _ptr(out["dbmu2"]),
+        _ptr(out["dbsig2"]), _ptr(out["dminit"]), _ptr(out["dsinit"]), _ptr(out["dimean"]), _ptr(out["disig"]),
+        _ptr(out["dsigc_f"]), _ptr(out["dsigc_g"]), _ptr(out["dsigc_q1inv"]), _ptr(dXs), _stream())
+    _mark("psvo_bsimwr_backward_cov", 1)
+    _lib.check(st, "psvo_bsimwr_backward_cov")
+    del k1, k2, k3
+
+    def head_grads(p, X, rows_mu, rows_sig, Dout):
+        W1, b1, Wm, bm, Ws, bs_ = p
+        gm = split_mlp_grad(mlp_wgrad(X, rows_mu, (W1, b1, Wm, bm), Dx, H, Dout), Dx, H, Dout)
+        gs_ = split_mlp_grad(mlp_wgrad(X, rows_sig, (W1, b1, Ws, bs_), Dx, H, Dout), Dx, H, Dout)
+        return (gm[0] + gs_[0], gm[1] + gs_[1], gm[2], gm[3], gs_[2], gs_[3])
+    out["gf"] = head_grads(f, out["xt"][:T - 1], out["dFt"][:T - 1], out["dFts"][:T - 1], Dx)
+    out["gg"] = head_grads(g, out["xt"], out["dGt"], out["dGts"], Dy)
+    out["gq1inv"] = head_grads(q1_inv, bs["bwXanc"][1:], out["dmu1"][:T - 1], out["dmu1s"][:T - 1], Dx)
+    return out
+
+
 def _chain_rows(out, z, T, B, Dx, N):
     """per-chain rows of d bmu2 (T,B,Dx,N), d minit and d imean (B,Dx,N) in ONE buffer, so that one reduction over the
     chains serves all three (they sit on the dependent chain in front of the encoder BPTT)"""

@@ -66,7 +66,7 @@ def test_invalid_arguments_are_rejected_without_a_device(built_lib):
         assert lib.psvo_bsim_blocks(ctypes.byref(d)) == _lib.PSVO_ERR_UNSUPPORTED
         for name in ("psvo_filter_backward", "psvo_bsim_forward", "psvo_bsim_backward", "psvo_bsimwr_forward",
                      "psvo_bsimwr_backward", "psvo_filter_forward_cov", "psvo_filter_backward_cov", "psvo_bsim_forward_cov",
-                     "psvo_bsim_backward_cov"):
+                     "psvo_bsim_backward_cov", "psvo_bsimwr_forward_cov", "psvo_bsimwr_backward_cov"):
             fn = getattr(lib, name)
             null = lambda ty: 0 if ty in (ctypes.c_int, ctypes.c_longlong) else 0.0 if ty in (ctypes.c_float, ctypes.c_double) else None
             args = [ctypes.byref(d)] + [null(ty) for ty in _lib.SIGNATURES[name][1][1:]]
@@ -76,7 +76,8 @@ def test_invalid_arguments_are_rejected_without_a_device(built_lib):
     for layers, emission, want in ((2, 0, _lib.PSVO_ERR_UNSUPPORTED), (1, 1, _lib.PSVO_ERR_INVALID),
                                    (1, 0, _lib.PSVO_ERR_INVALID)):
         d.layers, d.emission = layers, emission
-        for name in ("psvo_filter_forward_cov", "psvo_filter_backward_cov", "psvo_bsim_forward_cov", "psvo_bsim_backward_cov"):
+        for name in ("psvo_filter_forward_cov", "psvo_filter_backward_cov", "psvo_bsim_forward_cov", "psvo_bsim_backward_cov",
+                     "psvo_bsimwr_forward_cov", "psvo_bsimwr_backward_cov"):
             assert getattr(lib, name)(ctypes.byref(d), *nul_cov(name)) == want, (name, layers, emission)
     d.layers, d.emission = 1, 0
     assert lib.psvo_filter_cov_ws_floats(2, 4, 8, 2, 1) == 2 * 5 + 2 * 4 * 2 * 2 * 8

@@ -149,7 +149,7 @@ def test_trainer_improves_elbo(built_lib, tmp_path, monkeypatch, objective, hipg
     assert (len(graphs) == 1 and all(g is not False for g in graphs.values())) if hipgraph == "1" else not graphs
 
 
-@pytest.mark.parametrize("objective,hipgraph", [("PSVO", "1"), ("PSVO", "0"), ("AESMC", "1")])
+@pytest.mark.parametrize("objective,hipgraph", [("PSVO", "1"), ("PSVO", "0"), ("AESMC", "1"), ("PSVOwR", "1")])
 def test_trainer_with_state_dependent_scales(built_lib, tmp_path, monkeypatch, objective, hipgraph):
     """output_cov and diag_cov through the mirrored trainer (flat parameter buffer incl. the sigma_layer heads, Adam, the
     local step replayed from a hipGraph or issued eagerly): the ELBO goes up and the evaluation chain runs"""

@@ -486,6 +486,14 @@ COV_CASES = [
     (("PSVO", 2, 6, 16, 8, 2, 1, 32, False, True), dict(_COV, q1_layers="24", f_layers="40", g_layers="16", q0_layers="20",
                                                         q2_layers="50")),
     (("PSVO", 2, 6, 16, 8, 2, 1, 32, True, True), dict(_COV, BSim_use_single_RNN=True, y_smoother_Dhs="8,16")),
+    # ... and with resampling across the chains (psvo_bsimwr_forward_cov / _backward_cov: one launch per time step)
+    (("PSVOwR", 2, 6, 8, 4, 2, 1, 16, True, True), _COV),
+    (("PSVOwR", 2, 7, 64, 16, 2, 1, 32, True, True), _COV),
+    (("PSVOwR", 2, 6, 50, 8, 3, 1, 32, True, True), _COV),
+    (("PSVOwR", 1, 5, 36, 32, 4, 2, 32, False, True), _COV),
+    (("PSVOwR", 2, 5, 130, 16, 2, 1, 64, True, False), _COV),
+    (("PSVOwR", 1, 5, 20, 4, 3, 1, 32, False, False), _COV),
+    (("PSVOwR", 2, 5, 12, 4, 2, 1, 16, True, True), dict(_COV, poisson_emission=True)),
 ]
 
 
@@ -497,10 +505,10 @@ def test_state_dependent_scales(built_lib, case, extra):
 
 
 def test_state_dependent_scales_refusals(built_lib):
-    """what is NOT built says so: the backward simulation WITH RESAMPLING with output_cov, and two hidden layers with output_cov"""
-    FLAGS, model, smc, obs, noise = _setup("PSVOwR", 2, 5, 8, 4, 2, 1, 32, True, True, **_COV)
+    """what is NOT built says so: two hidden layers with output_cov, the full-covariance form"""
+    from psvo_amd.transformation.MLP import MLP_transformation
     with pytest.raises(NotImplementedError):
-        smc.get_log_ZSMC(obs.float().cuda(), None, noise=Hh.noise_to_hip(noise, "cuda"))
+        MLP_transformation([8], 2, 2, output_cov=True, diag_cov=False)
     FLAGS, model, smc, obs, noise = _setup("AESMC", 2, 5, 8, 1, 2, 1, 32, True, True, **dict(_COV, q1_layers="32,32",
                                                                                             g_layers="32,32"))
     with pytest.raises(ValueError):
