@@ -17,6 +17,7 @@
 // particle) are reduced over the lanes of a wave with DPP adds, over the waves of the workgroup with LDS float atomics and over
 // the workgroups of a sequence with global float atomics (the summation order is not fixed: gradients are reproducible to
 // rounding, not bit for bit).
+// PSVOwR (src/SMC/PSVOwR.py:65-198) runs the same kernels in a with-resampling mode (template flag WR), one launch per step.
 #include "common.h"
 
 namespace psvo {
