@@ -22,7 +22,7 @@ K32 = 4.0          # accepted multiple of the fp32 oracle's own error (see _run)
 TWO = [(dx, dy, h, m) for dx, dy, h, m in itertools.product((2, 3, 4), (1, 2), (32, 64), (4, 8, 16, 32))]
 
 
-def _run(obj, dx, dy, h, m, layers, k, N=None):
+def _run(obj, dx, dy, h, m, layers, k, N=None, cov=False):
     # alternate the wirings over the sweep so that every family also meets !bootstrap / !two_q; N varies a little
     boot, twoq = (k % 3 != 1), (k % 4 != 3)
     N = (20, 36, 12)[k % 3] if N is None else N
@@ -31,6 +31,8 @@ def _run(obj, dx, dy, h, m, layers, k, N=None):
     extra = dict(q1_layers=hp, g_layers=hp)
     if not boot:
         extra["f_layers"] = hp
+    if cov:
+        extra.update(output_cov=True, diag_cov=True)
     FLAGS, model, smc, obs, noise = TP._setup(*case, seed=3 + k % 5, **extra)
     _, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
     teacher = {"idx_f": ref0["idx_f"]} if ref0["idx_f"] is not None else {}
@@ -105,3 +107,19 @@ def test_every_wide_psvowr_instantiation(built_lib, k, combo, layers):
     if layers == 2 and h == 16:
         pytest.skip("two hidden layers: widths 32 and 64")
     _run("PSVOwR", dx, dy, h, 16, layers, k, N=130)
+
+
+# The state-dependent-scale kernels (output_cov and diag_cov: filter_cov.hip, bsim_cov.hip): every (Dx, Dy, H, M) of the
+# persistent PSVO form (filter_cov_fwd / _bwd in the 256-thread build, bsim_cov_fwd / _bwd) and of the launch-per-step PSVOwR
+# form (the WR = true builds), and the 512-thread filter build (N = 300) under the filter-only objectives.
+@pytest.mark.parametrize("obj", ["PSVO", "PSVOwR"])
+@pytest.mark.parametrize("k,combo", list(enumerate(ONE)), ids=lambda v: "-".join(map(str, v)) if isinstance(v, tuple) else None)
+def test_every_state_dependent_scale_instantiation(built_lib, obj, k, combo):
+    _run(obj, *combo, layers=1, k=k, cov=True)
+
+
+@pytest.mark.parametrize("N", [40, 300])
+@pytest.mark.parametrize("k,combo", list(enumerate(FILTER)), ids=lambda v: "-".join(map(str, v)) if isinstance(v, tuple) else None)
+def test_every_state_dependent_scale_filter_instantiation(built_lib, k, combo, N):
+    dx, dy, h = combo
+    _run(("AESMC", "IWAE", "SVO")[k % 3], dx, dy, h, 4, 1, k + N, N=N, cov=True)
