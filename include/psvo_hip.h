@@ -103,6 +103,9 @@ const char* psvo_status_string(int status);
 /*   PSVO_TUNE_L2_SPLIT: two-hidden-layer builds of psvo_bsim_forward / _backward: 0 (default) one lane per (chain, m);
  *   1 = a chain spread over 2 M lanes for small problems, as the one-layer builds do.  Set before sizing buffers. */
 #define PSVO_TUNE_L2_SPLIT 3
+/*   PSVO_TUNE_WGRAD2: psvo_mlp2_wgrad's H x H products: 0 (default) = v_mfma_f32_16x16x4_f32; 2 / 3 = bf16 matrix
+ *   instructions with every f32 operand split into two / three bf16 pieces (products carried to 2^-17 / 2^-24 relative). */
+#define PSVO_TUNE_WGRAD2 5
 /*   PSVO_TUNE_SKEW: start-up phase offset between the workgroups that share a CU in the backward-simulation kernels, in
  *   per cent of the kernel's estimate of its pair-phase length (default 0 = all workgroups start together: measured, it
  *   changes nothing -- profiles/r03_bsim_bwd_C5_ab.md -- and is kept as an A/B knob). */

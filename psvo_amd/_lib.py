@@ -17,6 +17,7 @@ PSVO_TUNE_BSIM_BWD = 1      # psvo_set_tuning keys (include/psvo_hip.h)
 PSVO_TUNE_ROWS_BWD = 2
 PSVO_TUNE_L2_SPLIT = 3
 PSVO_TUNE_SKEW = 4
+PSVO_TUNE_WGRAD2 = 5
 
 
 class PsvoHipError(RuntimeError):
@@ -120,6 +121,9 @@ def load():
         v = os.environ.get("PSVO_SKEW")                  # A/B: phase offset of co-resident workgroups, per cent (0 = off)
         if v is not None and lib.psvo_set_tuning(PSVO_TUNE_SKEW, int(v)) != PSVO_OK:
             raise PsvoHipError("PSVO_SKEW=%s is not a valid psvo_set_tuning value" % v)
+        v = os.environ.get("PSVO_WGRAD2")                # A/B: two-layer weight gradients on the bf16 matrix instructions (2 / 3 pieces)
+        if v is not None and lib.psvo_set_tuning(PSVO_TUNE_WGRAD2, int(v)) != PSVO_OK:
+            raise PsvoHipError("PSVO_WGRAD2=%s is not a valid psvo_set_tuning value" % v)
         v = os.environ.get("PSVO_L2_SPLIT")              # A/B: two-layer backward-simulation kernels with the half-split chains
         if v is not None and lib.psvo_set_tuning(PSVO_TUNE_L2_SPLIT, int(v)) != PSVO_OK:
             raise PsvoHipError("PSVO_L2_SPLIT=%s is not a valid psvo_set_tuning value" % v)

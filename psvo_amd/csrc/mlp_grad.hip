@@ -367,14 +367,336 @@ __global__ void __launch_bounds__(256) mlp2_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same three products on the bf16 matrix instructions with every f32 operand SPLIT into NP bf16 pieces
+// (x ~ hi + lo (+ lo2), each piece the round-to-nearest bf16 of the remainder: 8 significand bits per piece), so that the f32
+// product is carried to ~2^-17 (NP = 2: hh + hl + lh) or ~2^-24 (NP = 3: hh, hm, mh, hl, lh, mm) relative -- psvo_set_tuning(
+// PSVO_TUNE_WGRAD2, 2 | 3); 0 = the f32 instruction above (default until measured faster).  Why: v_mfma_f32_16x16x4_f32 runs at
+// 64 flop / cycle / SIMD and does not co-execute with the VALU on gfx950 (profiles/r02_bsim_bwd_ab.md); the bf16 instructions
+// run at 1024 flop / cycle / SIMD and do -- six of them per f32 product are still 2.7 x less pipe time, three 5.3 x, and here
+// K = H = 32 / 64 (phases 1, 2) or K = the 16 rows of a wave (phase 3) amortises the split.
+//   * Wh is split ONCE per workgroup into two LDS operand images (K = first index for pre2 = h1 Wh, K = second index for
+//     d h1 = d pre2 Wh^T): lane (j, kslot) reads its eight K values of one piece with one ds_read_b128;
+//   * h1 / d pre2 rows are split on the fly when a wave reads its A operand (8 consecutive floats of its own row);
+//   * phase 3 (dWh += h1^T d pre2, K = rows) runs on v_mfma_f32_16x16x16_bf16 with K = the wave's OWN 16 rows: its B operand
+//     -- d pre2 of rows 4 g + e, column li -- is the accumulator layout phase 1 just left in the lane's registers, so it never
+//     touches LDS, needs no workgroup barrier, and every wave keeps a partial of all H x H / 256 tiles (summed over the four
+//     waves once, at the end).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 wg_bf8 __attribute__((ext_vector_type(8)));
+typedef short wg_s4 __attribute__((ext_vector_type(4)));
+
+// two f32 -> NP packed bf16 pairs (element 0 in the low half).  Every piece is the ROUND-TO-NEAREST bf16 of what the pieces
+// before it left (v_cvt_pk_bf16_f32; the remainder x - hi is exact in f32), so the error of the sum of the pieces is
+// unbiased: truncated pieces are all short of the value by up to 2^-16 (NP = 2), an error that adds up over the K = 64 products
+// of a dot product and over the 10^7 rows of a weight gradient instead of averaging out (the dW1 of the first version failed
+// the 1e-4 parity bar for that reason).
+typedef __bf16 wg_bf2 __attribute__((ext_vector_type(2)));
+typedef float wg_f2 __attribute__((ext_vector_type(2)));
+template <int NP>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NP]) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(wg_f2{a, b}, wg_bf2));
+        out[p] = pk;
+        if (p + 1 < NP) {
+            a -= __uint_as_float(pk << 16);
+            b -= __uint_as_float(pk & 0xffff0000u);
+        }
+    }
+}
+// the piece products of one f32 product, smallest first: index pairs (piece of A, piece of B)
+template <int NP> struct PieceProducts;
+template <> struct PieceProducts<2> { static constexpr int N = 3; static constexpr int a[3] = {0, 1, 0}, b[3] = {1, 0, 0}; };
+template <> struct PieceProducts<3> {
+    static constexpr int N = 6;
+    static constexpr int a[6] = {1, 0, 2, 0, 1, 0}, b[6] = {1, 2, 0, 1, 0, 0};
+};
+
+template <int DIN, int DOUT, int H, int NP>
+__global__ void __launch_bounds__(256) mlp2_wgrad_bf16_kernel(const WgradArgs a) {
+    using PP = PieceProducts<NP>;
+    constexpr int NCT = H / 16;               // 16-wide column tiles of an H-wide matrix
+    constexpr int NKB = H / 32;               // K blocks of 32 (phases 1, 2)
+    constexpr int LDH = H + 4;                // padded LDS row, 16-byte aligned
+    constexpr int oB1 = DIN * H, oWh = oB1 + H, oBh = oWh + H * H, oW2 = oBh + H, oB2 = oW2 + H * DOUT, NP2 = oB2 + DOUT;
+    constexpr int NV = DIN + 2 + DOUT;        // per-column sums: dW1 rows, db1, dbh, dW2 columns
+    constexpr int IMG = NKB * NCT * 64 * 4;   // dwords of one piece image of Wh (16 B per lane, K block and column tile)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* H1s = sm;                          // [64][LDH]
+    float* D2s = H1s + 64 * LDH;              // [64][LDH]   d pre2
+    unsigned* WB1 = reinterpret_cast<unsigned*>(D2s + 64 * LDH);   // [NP][NKB][NCT][64][4]  B of pre2 = h1 Wh   (K = k of Wh[k][j])
+    unsigned* WB2 = WB1 + NP * IMG;                                 // [NP][NKB][NCT][64][4]  B of d h1 = d pre2 Wh^T (K = k of Wh[j][k])
+    float* xs = reinterpret_cast<float*>(WB2 + NP * IMG);          // [64][DIN]
+    float* ds = xs + 64 * DIN;                // [64][DOUT]
+    float* w1s = ds + 64 * DOUT;              // W1 [DIN][H] | b1 [H]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    // ---- the two operand images of Wh: entry (kb, c, lane) = eight K values of column / row 16 c + li ----------------
+    for (int i = tid; i < NKB * NCT * 64; i += 256) {
+        const int ln = i & 63, c = (i >> 6) % NCT, kb = (i >> 6) / NCT;
+        const int j = 16 * c + (ln & 15), k0 = 32 * kb + 8 * (ln >> 4);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            unsigned q1[NP], q2[NP];
+            split_pair<NP>(a.w.Wh[(k0 + e) * H + j], a.w.Wh[(k0 + e + 1) * H + j], q1);
+            split_pair<NP>(a.w.Wh[j * H + k0 + e], a.w.Wh[j * H + k0 + e + 1], q2);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                WB1[p * IMG + i * 4 + e / 2] = q1[p];
+                WB2[p * IMG + i * 4 + e / 2] = q2[p];
+            }
+        }
+    }
+    for (int i = tid; i < DIN * H; i += 256) w1s[i] = a.w.W1[i];
+    for (int i = tid; i < H; i += 256) w1s[DIN * H + i] = a.w.b1[i];
+
+    float w2r[NCT][DOUT], bhr[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        bhr[c] = a.w.bh[c * 16 + li];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) w2r[c][o] = a.w.W2[(c * 16 + li) * DOUT + o];
+    }
+    wg_f4 accWh[NCT][NCT];      // this wave's partial of dWh: tile (rt, ct), rows = units of h1, columns = units of d pre2
+#pragma unroll
+    for (int rt = 0; rt < NCT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) accWh[rt][ct] = wg_f4{0.f, 0.f, 0.f, 0.f};
+    float gW2[NCT][DOUT], gW1[NCT][DIN], gbh[NCT], gb1[NCT], gb2[DOUT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        gbh[c] = gb1[c] = 0.f;
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) gW2[c][o] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) gW1[c][d] = 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) gb2[o] = 0.f;
+    __syncthreads();
+
+    // A operand of a K block: eight consecutive floats of the lane's row, split into NP pieces of four packed words
+    auto a_operand = [&](const float* row8, wg_bf8 (&out)[NP]) {
+        const float4 v0 = *reinterpret_cast<const float4*>(row8), v1 = *reinterpret_cast<const float4*>(row8 + 4);
+        unsigned q[4][NP];
+        split_pair<NP>(v0.x, v0.y, q[0]);
+        split_pair<NP>(v0.z, v0.w, q[1]);
+        split_pair<NP>(v1.x, v1.y, q[2]);
+        split_pair<NP>(v1.z, v1.w, q[3]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) out[p] = __builtin_bit_cast(wg_bf8, make_uint4(q[0][p], q[1][p], q[2][p], q[3][p]));
+    };
+
+    const long long R = a.S * a.L;
+    const long long nchunk = (R + 63) / 64;
+    for (long long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+        // ---- A: rows of the chunk, first layer ---------------------------------------------------
+        {
+            const long long r = ch * 64 + lane;
+            const bool in = r < R;
+            const long long sg = in ? r / a.L : 0;
+            const int l = in ? (int)(r - sg * a.L) : 0;
+            float x[DIN];
+#pragma unroll
+            for (int d = 0; d < DIN; ++d) x[d] = in ? a.X[(sg * DIN + d) * a.L + l] : 0.f;
+            if (wave == 0) {
+#pragma unroll
+                for (int d = 0; d < DIN; ++d) xs[lane * DIN + d] = x[d];
+#pragma unroll
+                for (int o = 0; o < DOUT; ++o) {
+                    const float g = in ? a.dOut[(sg * DOUT + o) * a.L + l] : 0.f;
+                    ds[lane * DOUT + o] = g;
+                    gb2[o] += g;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < H / 4; ++kk) {
+                const int k = wave * (H / 4) + kk;
+                float pre = w1s[DIN * H + k];
+#pragma unroll
+                for (int d = 0; d < DIN; ++d) pre = fmaf(x[d], w1s[d * H + k], pre);
+                H1s[lane * LDH + k] = fmaxf(pre, 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- 1: pre2 = h1 Wh + bh for rows 16 wave .. + 15 ----------------------------------------
+        wg_f4 acc[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[c] = wg_f4{bhr[c], bhr[c], bhr[c], bhr[c]};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            wg_bf8 ap[NP];
+            a_operand(H1s + (wave * 16 + li) * LDH + 32 * kb + 8 * lg, ap);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                wg_bf8 bp[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    bp[p] = __builtin_bit_cast(wg_bf8, *reinterpret_cast<const uint4*>(WB1 + p * IMG + ((kb * NCT + c) * 64 + lane) * 4));
+#pragma unroll
+                for (int q = 0; q < PP::N; ++q)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PP::a[q]], bp[PP::b[q]], acc[c], 0, 0, 0);
+            }
+        }
+        // accumulator layout: row i = 16 wave + 4 lg + r, column j = 16 c + li
+        float dpr[NCT][4];          // d pre2 of (row 4 lg + r, column 16 c + li): phase 3's B operand as it stands
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = wave * 16 + 4 * lg + r;
+            float dout[DOUT];
+#pragma unroll
+            for (int o = 0; o < DOUT; ++o) dout[o] = ds[i * DOUT + o];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float pre2 = acc[c][r];
+                const float h2 = fmaxf(pre2, 0.f);
+                float dp = 0.f;
+#pragma unroll
+                for (int o = 0; o < DOUT; ++o) {
+                    dp = fmaf(dout[o], w2r[c][o], dp);
+                    gW2[c][o] = fmaf(h2, dout[o], gW2[c][o]);
+                }
+                dp = pre2 > 0.f ? dp : 0.f;
+                gbh[c] += dp;
+                dpr[c][r] = dp;
+                D2s[i * LDH + c * 16 + li] = dp;
+            }
+        }
+        // (rows 16 wave .. + 15 of D2s are this wave's own: no workgroup barrier before step 2)
+        // ---- 2: d h1 = (d pre2) Wh^T, masked; dW1, db1 -----------------------------------------------
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[c] = wg_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            wg_bf8 ap[NP];
+            a_operand(D2s + (wave * 16 + li) * LDH + 32 * kb + 8 * lg, ap);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                wg_bf8 bp[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    bp[p] = __builtin_bit_cast(wg_bf8, *reinterpret_cast<const uint4*>(WB2 + p * IMG + ((kb * NCT + c) * 64 + lane) * 4));
+#pragma unroll
+                for (int q = 0; q < PP::N; ++q)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[PP::a[q]], bp[PP::b[q]], acc[c], 0, 0, 0);
+            }
+        }
+        float h1r[NCT][4];          // h1 of (row 4 lg + r, unit 16 c + li): phase 3's A operand
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = wave * 16 + 4 * lg + r;
+            float x[DIN];
+#pragma unroll
+            for (int d = 0; d < DIN; ++d) x[d] = xs[i * DIN + d];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float h1v = H1s[i * LDH + c * 16 + li];
+                h1r[c][r] = h1v;
+                const float dh = h1v > 0.f ? acc[c][r] : 0.f;
+                gb1[c] += dh;
+#pragma unroll
+                for (int d = 0; d < DIN; ++d) gW1[c][d] = fmaf(x[d], dh, gW1[c][d]);
+            }
+        }
+        // ---- 3: dWh += h1^T (d pre2) over the wave's own 16 rows (K = 4 lg + e) --------------------------
+        {
+            wg_s4 ha[NCT][NP], db[NCT][NP];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                unsigned qa[2][NP], qb[2][NP];
+                split_pair<NP>(h1r[c][0], h1r[c][1], qa[0]);
+                split_pair<NP>(h1r[c][2], h1r[c][3], qa[1]);
+                split_pair<NP>(dpr[c][0], dpr[c][1], qb[0]);
+                split_pair<NP>(dpr[c][2], dpr[c][3], qb[1]);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    ha[c][p] = __builtin_bit_cast(wg_s4, make_uint2(qa[0][p], qa[1][p]));
+                    db[c][p] = __builtin_bit_cast(wg_s4, make_uint2(qb[0][p], qb[1][p]));
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < NCT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int q = 0; q < PP::N; ++q)
+                        accWh[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ha[rt][PP::a[q]], db[ct][PP::b[q]],
+                                                                                  accWh[rt][ct], 0, 0, 0);
+        }
+        __syncthreads();      // H1s / xs / ds are rewritten by the next chunk
+    }
+
+    // ---- the workgroup's partial ------------------------------------------------------------------
+    float* dst = a.partial + (size_t)blockIdx.x * NP2;
+    float* red = sm;     // dWh: [4 waves][H][H]; then the column sums [16 groups][NV][H]
+    static_assert(2 * 64 * LDH + 2 * NP * IMG >= 4 * H * H && 2 * 64 * LDH + 2 * NP * IMG >= 16 * NV * H,
+                  "final reductions reuse the tile buffers");
+#pragma unroll
+    for (int rt = 0; rt < NCT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * H * H + (rt * 16 + 4 * lg + r) * H + ct * 16 + li] = accWh[rt][ct][r];
+    __syncthreads();
+    for (int p = tid; p < H * H; p += 256) dst[oWh + p] = (red[p] + red[H * H + p]) + (red[2 * H * H + p] + red[3 * H * H + p]);
+    __syncthreads();
+    const int grp = wave * 4 + lg;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int j = c * 16 + li;
+        float* rg = red + (size_t)grp * NV * H;
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) rg[d * H + j] = gW1[c][d];
+        rg[DIN * H + j] = gb1[c];
+        rg[(DIN + 1) * H + j] = gbh[c];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) rg[(DIN + 2 + o) * H + j] = gW2[c][o];
+    }
+    __syncthreads();
+    for (int p = tid; p < NV * H; p += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) v += red[(size_t)g * NV * H + p];
+        const int row = p / H, j = p - row * H;
+        if (row < DIN) dst[row * H + j] = v;
+        else if (row == DIN) dst[oB1 + j] = v;
+        else if (row == DIN + 1) dst[oBh + j] = v;
+        else dst[oW2 + j * DOUT + (row - DIN - 2)] = v;
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) {
+            const float v = wave_sum(gb2[o]);
+            if (lane == 0) dst[oB2 + o] = v;
+        }
+    }
+}
+
+int g_tune_wgrad2 = 0;      // psvo_set_tuning(PSVO_TUNE_WGRAD2, 0 | 2 | 3)
+
+template <int DIN, int DOUT, int H, int NP>
+static void launch_wgrad2_bf16(const WgradArgs& a, int nblk, hipStream_t s) {
+    const size_t lds = sizeof(float) * ((size_t)2 * 64 * (H + 4) + 2 * NP * (H / 32) * (H / 16) * 64 * 4 + 64 * (DIN + DOUT) +
+                                        (DIN + 1) * H);
+    hipLaunchKernelGGL((mlp2_wgrad_bf16_kernel<DIN, DOUT, H, NP>), dim3(nblk), dim3(256), lds, s, a);
+}
+
 template <int DIN, int DOUT>
 static int launch_wgrad2(const WgradArgs& a, int H, int nblk, float* out, int accumulate, hipStream_t s) {
     const int NP2 = DIN * H + H + H * H + H + H * DOUT + DOUT;
     const size_t lds = sizeof(float) * ((size_t)(H + 128) * (H + 1) + 64 * (DIN + DOUT) + (DIN + 1) * H);
     clear_hip_error();
-    if (H == 32) hipLaunchKernelGGL((mlp2_wgrad_kernel<DIN, DOUT, 32>), dim3(nblk), dim3(256), lds, s, a);
-    else if (H == 64) hipLaunchKernelGGL((mlp2_wgrad_kernel<DIN, DOUT, 64>), dim3(nblk), dim3(256), lds, s, a);
-    else return PSVO_ERR_UNSUPPORTED;
+    if (H != 32 && H != 64) return PSVO_ERR_UNSUPPORTED;
+    if (g_tune_wgrad2 == 2) {
+        if (H == 32) launch_wgrad2_bf16<DIN, DOUT, 32, 2>(a, nblk, s);
+        else launch_wgrad2_bf16<DIN, DOUT, 64, 2>(a, nblk, s);
+    } else if (g_tune_wgrad2 == 3) {
+        if (H == 32) launch_wgrad2_bf16<DIN, DOUT, 32, 3>(a, nblk, s);
+        else launch_wgrad2_bf16<DIN, DOUT, 64, 3>(a, nblk, s);
+    } else if (H == 32) hipLaunchKernelGGL((mlp2_wgrad_kernel<DIN, DOUT, 32>), dim3(nblk), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((mlp2_wgrad_kernel<DIN, DOUT, 64>), dim3(nblk), dim3(256), lds, s, a);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(NP2), dim3(64), 0, s, a.partial, nblk, NP2, out, accumulate);
     return launch_status();
 }

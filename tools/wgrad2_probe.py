@@ -21,6 +21,8 @@ SHAPES = [((200, 32, 2, 128, 16), 2, 64, 2), ((200, 32, 2, 128, 16), 2, 64, 1), 
 
 
 def main():
+    # PSVO_WGRAD2=2|3 (read by psvo_amd._lib): the bf16-split variants of the H x H products
+    print("PSVO_WGRAD2 =", os.environ.get("PSVO_WGRAD2", "0 (f32 matrix instruction)"))
     g = torch.Generator().manual_seed(0)
     for shape, Din, H, Dout in SHAPES:
         dshape = shape[:2] + (Dout,) + shape[3:]
