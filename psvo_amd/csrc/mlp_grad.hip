@@ -431,7 +431,10 @@ __global__ void __launch_bounds__(256) mlp2_wgrad_bf16_kernel(const WgradArgs a)
     float* ds = xs + 64 * DIN;                // [64][DOUT]
     float* w1s = ds + 64 * DOUT;              // W1 [DIN][H] | b1 [H]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (the wave index as a SCALAR: `if (wave == 0)` on a per-lane value becomes an EXEC-masked region, and under this kernel's
+    //  register pressure hipcc 7.2 put live-range-split copies ahead of its EXEC restore -- tools/exec_restore_check.py)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     // ---- the two operand images of Wh: entry (kb, c, lane) = eight K values of column / row 16 c + li ----------------
     for (int i = tid; i < NKB * NCT * 64; i += 256) {
