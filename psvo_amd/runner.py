@@ -104,4 +104,5 @@ def main(FLAGS):
         with open(run_dir + "data.p", "wb") as fh:
             pickle.dump({"testing_data_dict": {"hidden_test": hidden_test[:keep], "obs_test": obs_test[:keep]},
                          "learned_model_dict": {"Xs_val": Xs_val, "y_hat_val": y_hat_val}}, fh)
+    fit.close_session()
     return history

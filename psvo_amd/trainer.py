@@ -232,7 +232,13 @@ class trainer:
         return {"X_trajs": X_trajs, "X": X, "nextX": nextX}
 
     def close_session(self):
-        pass
+        """the reference closes its tf.Session here (trainer.py:197-198).  Here: release the captured hipGraphs of the training
+        step at a quiescent point -- after a device synchronisation, by the caller -- instead of whenever the cycle collector
+        reaches this object, which may be in the middle of another trainer's replays (runner.main calls it on its way out)."""
+        graphs = self.__dict__.pop("_graphs", None)
+        if graphs:
+            torch.cuda.synchronize()
+            graphs.clear()
 
     def evaluate_and_save_metrics(self, iter_num, y_hat_N_BxTxDy=None, y_N_BxTxDy=None):
         """ELBO and k-step R-square on the training and held-out sets; appended to the histories and pickled as
