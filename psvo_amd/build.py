@@ -12,7 +12,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpsvo_hip.so")
 # (longest compiles first: with 8 parallel hipcc jobs the build then ends when the work does, not when a late-started
 #  psvowr_bwd unit does; the *_l2 units are the same sources compiled with PSVO_L = 2 -- two hidden layers per particle MLP)
-SOURCES = ["psvowr_bwd_l2.hip", "psvowr_bwd.hip", "bsim_cov.hip", "bsim_bwd_dx4_l2.hip", "bsim_fwd_l2.hip", "bsim_fwd.hip",
+SOURCES = ["bsim_cov.hip", "psvowr_bwd_l2.hip", "psvowr_bwd.hip", "bsim_bwd_dx4_l2.hip", "bsim_fwd_l2.hip", "bsim_fwd.hip",
            "bsim_bwd_dx2_l2.hip", "bsim_bwd_dx3_l2.hip", "psvowr_fwd.hip", "psvowr_fwd_l2.hip", "bsim_bwd_dx4.hip",
            "bsim_bwd_dx2.hip", "bsim_bwd_dx3.hip", "filter_bwd_l2.hip", "bsim_bwd2_dx2.hip", "filter_bwd.hip",
            "filter_fwd_l2.hip", "filter_cov.hip", "filter_fwd.hip", "bsim_bwd2_dx4.hip", "bsim_bwd2_dx3.hip", "mlp_grad.hip", "lstm_bwd.hip",
