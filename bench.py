@@ -46,6 +46,7 @@ WORKLOADS = {
     "C*-cov": ("PSVO", 32, 200, 128, 2, 1, 16, 32, 32, 1, True),
     "C2-cov": ("AESMC", 16, 200, 64, 2, 1, 16, 32, 32, 1, True),
     "C*wR-cov": ("PSVOwR", 32, 200, 128, 2, 1, 16, 32, 32, 1, True),
+    "C5-cov": ("PSVO", 8, 1000, 512, 4, 1, 16, 32, 32, 1, True),
 }
 FP32_PEAK_TFLOPS = 157.3     # MI355X f32 vector peak == f32-input MFMA dense peak (MI355X_MICROARCH.md)
 EXP_PEAK = 9.8e12            # transcendental quarter rate, exp/s
