@@ -504,6 +504,34 @@ def test_state_dependent_scales(built_lib, case, extra):
     _variant_against_oracle(case, extra)
 
 
+@pytest.mark.parametrize("obj", ["PSVO", "PSVOwR", "SVO"])
+def test_state_dependent_scales_long_sequence(built_lib, obj):
+    """T = 120 under output_cov (teacher-forced indices): the reverse passes carry d mean / d scale through 120 scatter steps and
+    accumulate 120 steps of atomics -- ELBO and every gradient against the fp64 oracle"""
+    case = (obj, 2, 120, 24, 4, 2, 1, 32, True, True)
+    FLAGS, model, smc, obs, noise = _setup(*case, seed=13, **_COV)
+    _, ref0 = Hh.run_oracle(model, FLAGS, obj, obs, noise)
+    teacher = {"idx_f": ref0["idx_f"]}
+    if obj in ("PSVO", "PSVOwR"):
+        teacher["idx_b"] = ref0["idx_b"]
+    if obj == "PSVOwR":
+        teacher["idx_r"] = ref0["idx_r"]
+    z_ref, P = _oracle_grads(model, FLAGS, obj, obs, noise, teacher)
+    nz = Hh.noise_to_hip({**noise, **teacher}, "cuda")
+    for k in ("u_f", "u_b", "u_r"):
+        nz.pop(k, None)
+
+    def hip_pass():
+        model.zero_grad()
+        zz, _ = smc.get_log_ZSMC(obs.float().cuda(), None, noise=nz)
+        zz.backward()
+        torch.cuda.synchronize()
+        return zz
+    zz = hip_pass()
+    assert abs(float(zz.detach()) - float(z_ref)) <= 1e-4 * abs(float(z_ref))
+    _check_grads(model, P, rerun=hip_pass)
+
+
 def test_state_dependent_scales_refusals(built_lib):
     """what is NOT built says so: two hidden layers with output_cov, the full-covariance form"""
     from psvo_amd.transformation.MLP import MLP_transformation
