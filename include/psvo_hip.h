@@ -106,6 +106,11 @@ const char* psvo_status_string(int status);
 /*   PSVO_TUNE_WGRAD2: psvo_mlp2_wgrad's H x H products: 0 (default) = v_mfma_f32_16x16x4_f32; 2 / 3 = bf16 matrix
  *   instructions with every f32 operand split into two / three bf16 pieces (products carried to 2^-17 / 2^-24 relative). */
 #define PSVO_TUNE_WGRAD2 5
+/*   PSVO_TUNE_FILTER_BWD: psvo_filter_backward in the bootstrap wiring with resampling (one hidden layer): 1 (default) = the
+ *   affine scan (coefficients of every step in parallel, one or four waves per sequence for the recurrence, rows in
+ *   parallel) where it pays -- no upstream gradient from a backward simulation, or N > 256 --, 2 = the scan wherever it
+ *   applies, 0 = the persistent reverse kernel (one workgroup per sequence), which every other wiring uses. */
+#define PSVO_TUNE_FILTER_BWD 6
 /*   PSVO_TUNE_SKEW: start-up phase offset between the workgroups that share a CU in the backward-simulation kernels, in
  *   per cent of the kernel's estimate of its pair-phase length (default 0 = all workgroups start together: measured, it
  *   changes nothing -- profiles/r03_bsim_bwd_C5_ab.md -- and is kept as an A/B knob). */

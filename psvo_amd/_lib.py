@@ -18,6 +18,7 @@ PSVO_TUNE_ROWS_BWD = 2
 PSVO_TUNE_L2_SPLIT = 3
 PSVO_TUNE_SKEW = 4
 PSVO_TUNE_WGRAD2 = 5
+PSVO_TUNE_FILTER_BWD = 6
 
 
 class PsvoHipError(RuntimeError):
@@ -121,6 +122,9 @@ def load():
         v = os.environ.get("PSVO_SKEW")                  # A/B: phase offset of co-resident workgroups, per cent (0 = off)
         if v is not None and lib.psvo_set_tuning(PSVO_TUNE_SKEW, int(v)) != PSVO_OK:
             raise PsvoHipError("PSVO_SKEW=%s is not a valid psvo_set_tuning value" % v)
+        v = os.environ.get("PSVO_FILTER_BWD_SCAN")       # A/B: 0 = the persistent reverse filter kernel instead of the affine scan
+        if v is not None and lib.psvo_set_tuning(PSVO_TUNE_FILTER_BWD, int(v)) != PSVO_OK:
+            raise PsvoHipError("PSVO_FILTER_BWD_SCAN=%s is not a valid psvo_set_tuning value" % v)
         v = os.environ.get("PSVO_WGRAD2")                # A/B: two-layer weight gradients on the bf16 matrix instructions (2 / 3 pieces)
         if v is not None and lib.psvo_set_tuning(PSVO_TUNE_WGRAD2, int(v)) != PSVO_OK:
             raise PsvoHipError("PSVO_WGRAD2=%s is not a valid psvo_set_tuning value" % v)

@@ -41,12 +41,16 @@ int set_rows_bwd_rb(int v);     // rows_mlp.hip
 int get_rows_bwd_rb();
 }  // namespace psvo
 
-namespace psvo { int g_tune_l2_split = 0; int g_tune_skew_pct = 0; }
+namespace psvo { int g_tune_l2_split = 0; int g_tune_skew_pct = 0; int g_tune_filter_bwd_scan = 1; }
 
 namespace psvo { extern int g_tune_wgrad2; }
 
 extern "C" int psvo_set_tuning(int key, int value) {
     if (key == PSVO_TUNE_ROWS_BWD) return psvo::set_rows_bwd_rb(value);
+    if (key == PSVO_TUNE_FILTER_BWD && value >= 0 && value <= 2) {
+        psvo::g_tune_filter_bwd_scan = value;
+        return PSVO_OK;
+    }
     if (key == PSVO_TUNE_WGRAD2 && (value == 0 || value == 2 || value == 3)) {
         psvo::g_tune_wgrad2 = value;
         return PSVO_OK;
@@ -71,6 +75,7 @@ extern "C" int psvo_get_tuning(int key) {
     if (key == PSVO_TUNE_L2_SPLIT) return psvo::g_tune_l2_split;
     if (key == PSVO_TUNE_SKEW) return psvo::g_tune_skew_pct;
     if (key == PSVO_TUNE_WGRAD2) return psvo::g_tune_wgrad2;
+    if (key == PSVO_TUNE_FILTER_BWD) return psvo::g_tune_filter_bwd_scan;
     return key == PSVO_TUNE_BSIM_BWD ? g_bsim_bwd_variant : PSVO_ERR_INVALID;
 }
 

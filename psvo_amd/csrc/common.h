@@ -52,6 +52,9 @@ inline bool desc_layers_ok(const psvo_desc* d) { return !d || (d->layers >= 0 &&
 // builds do.  (With the H x H layer on the matrix pipe a second wave per SIMD shares that pipe and the per-row overheads
 // double: measured)
 extern int g_tune_l2_split;
+// PSVO_TUNE_FILTER_BWD (psvo_set_tuning): 1 (default) = the reverse filter as an affine scan where it applies (bootstrap wiring
+// with resampling, one hidden layer: filter_bwd.hip) AND pays, 2 = wherever it applies, 0 = the persistent reverse kernels always
+extern int g_tune_filter_bwd_scan;
 
 // PSVO_TUNE_SKEW (psvo_set_tuning): phase offset between the workgroups that share a CU, in per cent of the kernel's own
 // estimate of its pair-phase length (0 = off = default).  See phase_skew().

@@ -36,6 +36,8 @@ struct FilterBwdArgs {
     float* sacc;             // (B, NACC) per-sequence scalar accumulators (see finalize)
     float* dm2_rows;         // (T,B,Dx,N) per-particle d mu2 rows, summed over N by row_sum_kernel afterwards
     int wave_copies;         // filter_bwd_kernel: one scatter-target copy per wave (set by the launcher when LDS has room)
+    float* scanAB;           // affine-scan path: (T,B,Dx*Dx+Dx,N) coefficients; part: (T,B,NACC) per-step partial sums
+    float* scanPart;
 };
 
 template <int DX, int DY>
@@ -842,6 +844,350 @@ __global__ void __launch_bounds__(256) row_sum_kernel(const float* __restrict__ 
     if (lane == 0) out[r] = s;
 }
 
+#if PSVO_L == 1
+// ---------------------------------------------------------------------------------------------
+// The reverse filter as an AFFINE SCAN (round 3; bootstrap wiring with resampling, one hidden layer).
+//
+// With resampling the gradient w.r.t. logW_t[n] does not depend on later steps, and the only thing the reverse pass carries
+// from step t+1 to step t is D_t[n] = d loss / d MLP_q1(x_t[n]) (Dx values per particle): the children of particle n scatter
+//     kappa (dx0_c + J_c^T D_{t+1}[c]) + tf_c        into D_t[n]   (c: particles of step t+1 with ancestor n)
+// where J_c = d MLP_q1 / d x at x_{t+1}[c], dx0_c and tf_c the parts of the step that do not depend on D, kappa = c / s1 the
+// product-of-Gaussians factor.  The recurrence is AFFINE in D:  D_t[n] = ext_t[n] + sum_c (A_c D_{t+1}[c] + b_c)  with a
+// Dx x Dx matrix A_c = diag(kappa) J_c^T and a vector b_c per particle and step.  So the time loop splits into
+//   A. fbs_coeff_kernel : A and b of EVERY (t, b, n) -- the MLP_g forward + input gradient, the densities and Dx input-gradient
+//      passes of MLP_q1 on unit vectors -- one workgroup per (t, sequence): T B workgroups on all CUs, no dependence between them;
+//   B. fbs_scan_kernel  : ONE WAVE per sequence walks t = T-1 .. 0 doing nothing but D <- ext + scatter(A D + b): a Dx x Dx
+//      matrix-vector product and Dx LDS adds per particle and step, no MLP, no barrier (a single wave: LDS operations are in
+//      order), coefficients requested a step ahead; it writes the rows D_t[n] (= the dP rows of psvo_mlp_wgrad);
+//   C. fbs_rows_kernel  : everything else the persistent kernel produces, from D -- dG rows, d mu2 rows, the scale sums, d m0 --
+//      again one workgroup per (t, sequence).
+// The persistent kernel spends 7 800 cycles per step on ONE workgroup per sequence (32 of 256 CUs at C*, 8 at C5) and only a
+// quarter of that is MLP arithmetic; here the serial part is ~10 instructions per particle and step.
+// Sums are fixed-order (per-step partials folded over t by fbs_fold_kernel; LDS adds of one wave are applied in lane order).
+// ---------------------------------------------------------------------------------------------
+template <int DX, int DY, int H>
+__global__ void __launch_bounds__(512) fbs_coeff_kernel(const FilterBwdArgs a) {
+    using MQ = MlpLds<DX, H, DX, 1>;
+    using MG = MlpLds<DX, H, DY, 1>;
+    constexpr bool kRolled = true;
+    constexpr int NC = DX * DX + DX;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int t = blockIdx.x + 1, b = blockIdx.y, B = a.B, N = a.N;      // (t = 0 has no parent: no coefficients)
+    const bool valid = tid < N;
+    const int n = valid ? tid : N - 1;
+    float* wq1 = smem;
+    float* wg = wq1 + MQ::kSize;
+    MQ::load(wq1, a.q1, tid, NT);
+    MG::load(wg, a.g, tid, NT);
+    const size_t tb = (size_t)t * B + b;
+    float x[DX], fmean[DX], y[DY];
+    const int anc = a.idx[(tb - B) * N + n];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        x[d] = a.X[(tb * DX + d) * N + n];
+        fmean[d] = a.Fm[((tb - B) * DX + d) * N + anc];
+    }
+#pragma unroll
+    for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+    const float sm = exp2_fast((a.logW[tb * N + n] - a.lse[tb]) * kLog2e);
+    const float dlw = (a.dlse ? a.dlse[tb] : 0.f) * sm + (a.dlogW_ext ? a.dlogW_ext[tb * N + n] : 0.f);
+    float kap[DX], ifs[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        const float i1 = 1.f / a.sig_q1[d];
+        kap[d] = a.two_q ? i1 / (i1 + 1.f / a.sig_q2[d]) : 1.f;     // c / s1
+        ifs[d] = i1;                                                // bootstrap: the transition scale is sigma_q1
+    }
+    __syncthreads();
+    float dxg[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) dxg[d] = 0.f;
+    {
+        float gm[DY], dgm[DY];
+        MG::template eval<kRolled>(wg, x, gm);
+#pragma unroll
+        for (int k = 0; k < DY; ++k) {
+            float dmean = 1.f;
+            if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
+            const float isg = 1.f / a.sig_g[k];
+            dgm[k] = dlw * (y[k] - gm[k]) * isg * isg * dmean;
+        }
+        MG::template bwd_input<kRolled>(wg, x, dgm, dxg);
+    }
+    float cf[NC];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        const float tf = dlw * (x[d] - fmean[d]) * ifs[d] * ifs[d];
+        cf[DX * DX + d] = fmaf(kap[d], dxg[d] - tf, tf);
+    }
+#pragma unroll
+    for (int k = 0; k < DX; ++k) {
+        float ek[DX], col[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) { ek[d] = (d == k) ? 1.f : 0.f; col[d] = 0.f; }
+        MQ::template bwd_input<kRolled>(wq1, x, ek, col);          // J^T e_k
+#pragma unroll
+        for (int d = 0; d < DX; ++d) cf[d * DX + k] = kap[d] * col[d];
+    }
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) a.scanAB[(tb * NC + i) * N + n] = cf[i];
+    }
+}
+
+// NWV waves per sequence (1: no barrier at all -- LDS operations of one wave are in order; 4: one barrier per step), PPL particles
+// per lane (N <= 64 NWV PPL), DEPTH steps of coefficients in flight: a step takes ~0.2 us and HBM ~2 us, so the loads of step
+// t - DEPTH are issued when step t is consumed (a ring of DEPTH register sets, the step loop unrolled DEPTH times so that every
+// index into it is static).
+template <int DX, int NWV, int PPL, int DEPTH>
+__global__ void __launch_bounds__(64 * NWV) fbs_scan_kernel(const FilterBwdArgs a) {
+    constexpr int NC = DX * DX + DX, NTS = 64 * NWV;
+    // scatter targets: one copy per wave, summed by the parent in wave order (LDS adds of ONE wave are applied in lane order,
+    // adds of several waves in arrival order: with the copies every sum has a fixed order, as in filter_bwd_lpp_kernel)
+    extern __shared__ __attribute__((aligned(16))) float acc[];      // [2][NWV][DX][N]
+    const int tid = threadIdx.x, b = blockIdx.x, B = a.B, T = a.T, N = a.N;
+    const int CPY = DX * N, mine = (tid >> 6) * CPY;
+    for (int i = tid; i < 2 * NWV * CPY; i += NTS) acc[i] = 0.f;
+    float cf[DEPTH][PPL][NC], ext[DEPTH][PPL][DX];
+    int an[DEPTH][PPL];
+    auto load = [&](int t, float (&c)[PPL][NC], float (&e)[PPL][DX], int (&q)[PPL]) {
+        const size_t tb = (size_t)t * B + b;
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+            const int n = min(tid + NTS * p, N - 1);
+#pragma unroll
+            for (int d = 0; d < DX; ++d) e[p][d] = a.dFm_ext ? a.dFm_ext[(tb * DX + d) * N + n] : 0.f;
+            if (t >= 1) {
+                q[p] = a.idx[(tb - B) * N + n];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) c[p][i] = a.scanAB[(tb * NC + i) * N + n];
+            }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s)
+        if (T - 1 - s >= 0) load(T - 1 - s, cf[s], ext[s], an[s]);
+    if (NWV > 1) __syncthreads();
+    for (int t0 = T - 1; t0 >= 0; t0 -= DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            const int t = t0 - s;
+            if (t < 0) break;
+            const size_t tb = (size_t)t * B + b;
+            float* cur = acc + (t & 1) * NWV * CPY;
+            float* nxt = acc + ((t + 1) & 1) * NWV * CPY + mine;
+            float D[PPL][DX];
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                const int n = tid + NTS * p;
+                if (n < N) {
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NWV; ++w) {
+                            v += cur[w * CPY + d * N + n];
+                            cur[w * CPY + d * N + n] = 0.f;
+                        }
+                        D[p][d] = v + ext[s][p][d];
+                        a.dP[(tb * DX + d) * N + n] = D[p][d];
+                    }
+                }
+            }
+            if (t >= 1) {
+#pragma unroll
+                for (int p = 0; p < PPL; ++p) {
+                    const int n = tid + NTS * p;
+                    if (n < N) {
+#pragma unroll
+                        for (int d = 0; d < DX; ++d) {
+                            float v = cf[s][p][DX * DX + d];
+#pragma unroll
+                            for (int k = 0; k < DX; ++k) v = fmaf(cf[s][p][d * DX + k], D[p][k], v);
+                            atomicAdd(&nxt[d * N + an[s][p]], v);
+                        }
+                    }
+                }
+            }
+            if (t - DEPTH >= 0) load(t - DEPTH, cf[s], ext[s], an[s]);      // refill the slot just consumed
+            if (NWV > 1) {
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+}
+
+template <int DX, int DY, int H>
+__global__ void __launch_bounds__(512) fbs_rows_kernel(const FilterBwdArgs a) {
+    using MQ = MlpLds<DX, H, DX, 1>;
+    using MG = MlpLds<DX, H, DY, 1>;
+    using AC = FAcc<DX, DY>;
+    constexpr bool kRolled = true;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x, nw = NT >> 6;
+    const int t = blockIdx.x, b = blockIdx.y, B = a.B, N = a.N;
+    const bool valid = tid < N, first = (t == 0);
+    const int n = valid ? tid : N - 1;
+    float* wq1 = smem;
+    float* wg = wq1 + MQ::kSize;
+    float* red = wg + MG::kSize;     // [nw][kN] + 16
+    MQ::load(wq1, a.q1, tid, NT);
+    MG::load(wg, a.g, tid, NT);
+    const size_t tb = (size_t)t * B + b;
+    float s1[DX], s2[DX], fs[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        s1[d] = first ? a.sig0[d] : a.sig_q1[d];
+        s2[d] = a.two_q ? a.sig_q2[d] : 1.f;
+        fs[d] = first ? a.fsig0[d] : a.sig_q1[d];
+    }
+    const BStepK<DX> K = make_bstepk<DX>(s1, s2, fs, a.two_q != 0);
+    float x[DX], e[DX], m2[DX], y[DY], mean1[DX], fmean[DX], dPn[DX];
+    const int anc = first ? n : a.idx[(tb - B) * N + n];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        x[d] = a.X[(tb * DX + d) * N + n];
+        e[d] = a.eps[(tb * DX + d) * N + n];
+        m2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
+        fmean[d] = first ? a.fm0[b * DX + d] : a.Fm[((tb - B) * DX + d) * N + anc];
+        mean1[d] = first ? a.m0[b * DX + d] : fmean[d];
+        dPn[d] = valid ? a.dP[(tb * DX + d) * N + n] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+    const float sm = valid ? exp2_fast((a.logW[tb * N + n] - a.lse[tb]) * kLog2e) : 0.f;
+    float dlw = (a.dlse ? a.dlse[tb] : 0.f) * sm + (a.dlogW_ext ? a.dlogW_ext[tb * N + n] : 0.f);
+    if (!valid) dlw = 0.f;
+    float mu[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) mu[d] = a.two_q ? K.c[d] * fmaf(K.i1[d], mean1[d], K.i2[d] * m2[d]) : mean1[d];
+    __syncthreads();
+
+    float acc[AC::kN];
+#pragma unroll
+    for (int i = 0; i < AC::kN; ++i) acc[i] = 0.f;
+    float inc[AC::kSet];
+#pragma unroll
+    for (int i = 0; i < AC::kSet; ++i) inc[i] = 0.f;
+    float dx[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) dx[d] = 0.f;
+    {
+        float gm[DY], dgm[DY];
+        MG::template eval<kRolled>(wg, x, gm);
+#pragma unroll
+        for (int k = 0; k < DY; ++k) {
+            float dmean = 1.f;
+            if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
+            const float isg = 1.f / a.sig_g[k];
+            const float z = (y[k] - gm[k]) * isg;
+            dgm[k] = dlw * z * isg * dmean;
+            acc[AC::kSg + k] += dlw * (z * z - 1.f) * isg;
+            if (valid) a.dG[(tb * DY + k) * N + n] = dgm[k];
+        }
+        MG::template bwd_input<kRolled>(wg, x, dgm, dx);
+    }
+    float dfmean[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        const float z = (x[d] - fmean[d]) * K.ifs[d];
+        const float tf = dlw * z * K.ifs[d];
+        dx[d] -= tf;
+        dfmean[d] = tf;
+        inc[AC::kSfs + d] += dlw * (z * z - 1.f) * K.ifs[d];
+        inc[AC::kSc + d] += dlw * K.ic[d];
+    }
+    MQ::template bwd_input<kRolled>(wq1, x, dPn, dx);
+    float dmean1[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        const float dmu = dx[d];
+        inc[AC::kSc + d] += dmu * e[d];
+        if (a.two_q) {
+            dmean1[d] = dmu * K.c[d] * K.i1[d];
+            inc[AC::kSmm1 + d] += dmu * mean1[d];
+            inc[AC::kSmb + d] += dmu * m2[d];
+            inc[AC::kSmm + d] += dmu * mu[d];
+            if (valid) a.dm2_rows[(tb * DX + d) * N + n] = dmu * K.c[d] * K.i2[d];
+        } else {
+            dmean1[d] = dmu;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < AC::kSet; ++i) acc[(first ? 0 : AC::kSet) + i] = inc[i];
+    // ---- this step's partial of the per-sequence sums (fixed order: lanes, then waves) ----------------------------------
+#pragma unroll
+    for (int i = 0; i < AC::kN; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave * AC::kN + i] = v;
+    }
+    if (first) {
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            const float v1 = wave_sum(dmean1[d]), v2 = wave_sum(dfmean[d]);
+            if (lane == 0) {
+                red[nw * AC::kN + wave * 2 * DX + d] = v1;
+                red[nw * AC::kN + wave * 2 * DX + DX + d] = v2;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < AC::kN) {
+        float v = 0.f;
+        for (int w = 0; w < nw; ++w) v += red[w * AC::kN + tid];
+        a.scanPart[tb * AC::kN + tid] = v;
+    }
+    if (first && tid < DX) {
+        float v1 = 0.f, v2 = 0.f;
+        for (int w = 0; w < nw; ++w) {
+            v1 += red[nw * AC::kN + w * 2 * DX + tid];
+            v2 += red[nw * AC::kN + w * 2 * DX + DX + tid];
+        }
+        const bool same0 = (a.fm0 == a.m0);
+        a.dm0[b * DX + tid] = same0 ? v1 + v2 : v1;
+        a.dfm0[b * DX + tid] = same0 ? 0.f : v2;
+    }
+}
+
+// sacc[b][i] = sum_t part[t][b][i]: one wave per (b, i) strides over t and sums its lanes in a fixed order
+__global__ void __launch_bounds__(256) fbs_fold_kernel(const float* __restrict__ part, int T, int B, int NACC,
+                                                       float* __restrict__ sacc) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < NACC; i += 4) {
+        float v = 0.f;
+        for (int t = lane; t < T; t += 64) v += part[((size_t)t * B + b) * NACC + i];
+        v = wave_sum(v);
+        if (lane == 0) sacc[(size_t)b * NACC + i] = v;
+    }
+}
+
+template <int DX, int DY, int H>
+static void launch_filter_bwd_scan(const FilterBwdArgs& a, hipStream_t stream) {
+    using MQ = MlpLds<DX, H, DX, 1>;
+    using MG = MlpLds<DX, H, DY, 1>;
+    using AC = FAcc<DX, DY>;
+    const int NT = (a.N + 63) & ~63;
+    const size_t ldsw = sizeof(float) * (MQ::kSize + MG::kSize);
+    if (a.T >= 2)
+        hipLaunchKernelGGL((fbs_coeff_kernel<DX, DY, H>), dim3(a.T - 1, a.B), dim3(NT), ldsw, stream, a);
+    const size_t ldss = sizeof(float) * 2 * DX * a.N * (a.N <= 128 ? 1 : 4);
+    // registers of the coefficient ring: DEPTH x PPL x (Dx^2 + 2 Dx + 1) -- <= ~300 of the 512 a lone wave per SIMD may use
+    constexpr int D1 = (DX == 2) ? 16 : (DX == 3) ? 12 : 8, D2 = D1 / 2;
+    if (a.N <= 64) hipLaunchKernelGGL((fbs_scan_kernel<DX, 1, 1, D1>), dim3(a.B), dim3(64), ldss, stream, a);
+    else if (a.N <= 128) hipLaunchKernelGGL((fbs_scan_kernel<DX, 1, 2, D2>), dim3(a.B), dim3(64), ldss, stream, a);
+    else if (a.N <= 256) hipLaunchKernelGGL((fbs_scan_kernel<DX, 4, 1, D1>), dim3(a.B), dim3(256), ldss, stream, a);
+    else hipLaunchKernelGGL((fbs_scan_kernel<DX, 4, 2, D2>), dim3(a.B), dim3(256), ldss, stream, a);
+    const size_t ldsr = ldsw + sizeof(float) * ((NT / 64) * (AC::kN + 2 * DX) + 16);
+    hipLaunchKernelGGL((fbs_rows_kernel<DX, DY, H>), dim3(a.T, a.B), dim3(NT), ldsr, stream, a);
+    hipLaunchKernelGGL(fbs_fold_kernel, dim3(a.B), dim3(256), 0, stream, a.scanPart, a.T, a.B, AC::kN, a.sacc);
+}
+#endif   // PSVO_L == 1
+
 struct FilterBwdOut {
     float *dsig_q1, *dsig_q2, *dsig_f, *dsig_g, *dsig0, *dfsig0;
 };
@@ -861,6 +1207,17 @@ static int launch_filter_bwd(const FilterBwdArgs& a, const FilterBwdOut& o, hipS
     clear_hip_error();
     constexpr bool kLppOk = (H % 16 == 0) && (PSVO_L == 2 || (H <= 32 && DX <= 3));   // (two layers: as in filter_fwd.hip)
     bool lpp = false;
+#if PSVO_L == 1
+    // Used where the reverse filter IS the tail of the step: the filter-only objectives (no upstream gradient from a backward
+    // simulation: C2 0.90 -> 0.67 ms) and N > 256 (one workgroup per sequence on 8 CUs at C5: 71.2 -> 66.7 ms).  Behind a
+    // backward simulation at N <= 256 the tail is bound by the weight gradients that run beside it -- C* 3.45 -> 3.42, C4
+    // unchanged -- and the persistent kernel stays (psvo_set_tuning(PSVO_TUNE_FILTER_BWD, 2) forces the scan everywhere).
+    const bool scan_pays = (!a.dFm_ext && !a.dlogW_ext) || a.N > 256 || g_tune_filter_bwd_scan == 2;
+    if (g_tune_filter_bwd_scan && scan_pays && a.bootstrap && a.resample && a.nparts <= 1 && a.scanAB && a.scanPart) {
+        launch_filter_bwd_scan<DX, DY, H>(a, stream);
+        lpp = true;      // (the persistent kernels are skipped)
+    } else
+#endif
     if constexpr (kLppOk) {
         if (a.N <= 128) {   // latency-bound regime: four lanes per particle
             const int NT4 = (4 * a.N + 63) & ~63;
@@ -912,7 +1269,9 @@ static int fb_dispatch_dy(const FilterBwdArgs& a, const FilterBwdOut& o, int Dy,
 extern "C" int psvo_filter_acc_size(int Dx, int Dy) { return 10 * Dx + Dy; }
 
 extern "C" long long psvo_filter_ws_floats(int B, int T, int N, int Dx, int Dy) {
-    return (long long)B * (10 * Dx + Dy) + (long long)T * B * Dx * N;
+    // per-sequence sums | d mu2 rows | affine-scan coefficients (T,B,Dx*Dx+Dx,N) | per-step partial sums (T,B,NACC)
+    return (long long)B * (10 * Dx + Dy) + (long long)T * B * Dx * N + (long long)T * B * (Dx * Dx + Dx) * N +
+           (long long)T * B * (10 * Dx + Dy);
 }
 #endif
 
@@ -956,6 +1315,8 @@ PSVO_ENTRY(psvo_filter_backward)(
     a.dlse = dlse; a.nparts = nparts; a.dFm_ext = dFm_ext; a.dlogW_ext = dlogW_ext;
     a.dP = dP; a.dF = dF; a.dG = dG; a.dmu2 = dmu2; a.dm0 = dm0; a.dfm0 = dfm0; a.sacc = sacc;
     a.dm2_rows = sacc + (size_t)desc->B * psvo_filter_acc_size(desc->Dx, desc->Dy);
+    a.scanAB = a.dm2_rows + (size_t)desc->T * desc->B * desc->Dx * desc->N;
+    a.scanPart = a.scanAB + (size_t)desc->T * desc->B * (desc->Dx * desc->Dx + desc->Dx) * desc->N;
     FilterBwdOut o{dsig_q1, dsig_q2, dsig_f, dsig_g, dsig0, dfsig0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {
