@@ -36,7 +36,7 @@ struct FilterBwdArgs {
     float* sacc;             // (B, NACC) per-sequence scalar accumulators (see finalize)
     float* dm2_rows;         // (T,B,Dx,N) per-particle d mu2 rows, summed over N by row_sum_kernel afterwards
     int wave_copies;         // filter_bwd_kernel: one scatter-target copy per wave (set by the launcher when LDS has room)
-    float* scanAB;           // affine-scan path: (T,B,Dx*Dx+Dx,N) coefficients; part: (T,B,NACC) per-step partial sums
+    float* scanAB;           // affine-scan path: (T,B,N,REC) records (16-byte aligned); part: (T,B,NACC) per-step partial sums
     float* scanPart;
 };
 
@@ -865,74 +865,96 @@ __global__ void __launch_bounds__(256) row_sum_kernel(const float* __restrict__ 
 // quarter of that is MLP arithmetic; here the serial part is ~10 instructions per particle and step.
 // Sums are fixed-order (per-step partials folded over t by fbs_fold_kernel; LDS adds of one wave are applied in lane order).
 // ---------------------------------------------------------------------------------------------
+// One record per (t, sequence, particle), stored as float4 planes [(t, sequence), float4 index, particle] so that the scan reads it
+// with 16-byte loads that are contiguous over the lanes:
+//   [ A (Dx x Dx, row-major) | b (Dx) | ext (Dx) = the upstream gradient w.r.t. Fm_t[n] | ancestor (int bits) ], padded to float4s.
+// (The first layout was (T,B,coefficient,N) read with one dword load per value: 25 loads per particle and step at Dx = 4 --
+//  a wave can have 64 vector-memory operations outstanding, so the scan ran ONE step ahead whatever its ring depth.)
+template <int DX>
+struct ScanRec {
+    static constexpr int NC = DX * DX + DX;
+    static constexpr int kExt = NC, kAnc = NC + DX;
+    static constexpr int REC = (NC + DX + 1 + 3) & ~3;
+};
+
 template <int DX, int DY, int H>
 __global__ void __launch_bounds__(512) fbs_coeff_kernel(const FilterBwdArgs a) {
     using MQ = MlpLds<DX, H, DX, 1>;
     using MG = MlpLds<DX, H, DY, 1>;
+    using SR = ScanRec<DX>;
     constexpr bool kRolled = true;
-    constexpr int NC = DX * DX + DX;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, NT = blockDim.x;
-    const int t = blockIdx.x + 1, b = blockIdx.y, B = a.B, N = a.N;      // (t = 0 has no parent: no coefficients)
+    const int t = blockIdx.x, b = blockIdx.y, B = a.B, N = a.N;
     const bool valid = tid < N;
     const int n = valid ? tid : N - 1;
-    float* wq1 = smem;
-    float* wg = wq1 + MQ::kSize;
-    MQ::load(wq1, a.q1, tid, NT);
-    MG::load(wg, a.g, tid, NT);
     const size_t tb = (size_t)t * B + b;
-    float x[DX], fmean[DX], y[DY];
-    const int anc = a.idx[(tb - B) * N + n];
+    float rec[SR::REC];
 #pragma unroll
-    for (int d = 0; d < DX; ++d) {
-        x[d] = a.X[(tb * DX + d) * N + n];
-        fmean[d] = a.Fm[((tb - B) * DX + d) * N + anc];
-    }
+    for (int i = 0; i < SR::REC; ++i) rec[i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
-    const float sm = exp2_fast((a.logW[tb * N + n] - a.lse[tb]) * kLog2e);
-    const float dlw = (a.dlse ? a.dlse[tb] : 0.f) * sm + (a.dlogW_ext ? a.dlogW_ext[tb * N + n] : 0.f);
-    float kap[DX], ifs[DX];
+    for (int d = 0; d < DX; ++d) rec[SR::kExt + d] = a.dFm_ext ? a.dFm_ext[(tb * DX + d) * N + n] : 0.f;
+    if (t >= 1) {       // (t = 0 has no parent: only the upstream gradient)
+        float* wq1 = smem;
+        float* wg = wq1 + MQ::kSize;
+        MQ::load(wq1, a.q1, tid, NT);
+        MG::load(wg, a.g, tid, NT);
+        float x[DX], fmean[DX], y[DY];
+        const int anc = a.idx[(tb - B) * N + n];
+        rec[SR::kAnc] = __int_as_float(anc);
 #pragma unroll
-    for (int d = 0; d < DX; ++d) {
-        const float i1 = 1.f / a.sig_q1[d];
-        kap[d] = a.two_q ? i1 / (i1 + 1.f / a.sig_q2[d]) : 1.f;     // c / s1
-        ifs[d] = i1;                                                // bootstrap: the transition scale is sigma_q1
-    }
-    __syncthreads();
-    float dxg[DX];
-#pragma unroll
-    for (int d = 0; d < DX; ++d) dxg[d] = 0.f;
-    {
-        float gm[DY], dgm[DY];
-        MG::template eval<kRolled>(wg, x, gm);
-#pragma unroll
-        for (int k = 0; k < DY; ++k) {
-            float dmean = 1.f;
-            if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
-            const float isg = 1.f / a.sig_g[k];
-            dgm[k] = dlw * (y[k] - gm[k]) * isg * isg * dmean;
+        for (int d = 0; d < DX; ++d) {
+            x[d] = a.X[(tb * DX + d) * N + n];
+            fmean[d] = a.Fm[((tb - B) * DX + d) * N + anc];
         }
-        MG::template bwd_input<kRolled>(wg, x, dgm, dxg);
-    }
-    float cf[NC];
 #pragma unroll
-    for (int d = 0; d < DX; ++d) {
-        const float tf = dlw * (x[d] - fmean[d]) * ifs[d] * ifs[d];
-        cf[DX * DX + d] = fmaf(kap[d], dxg[d] - tf, tf);
-    }
+        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+        const float sm = exp2_fast((a.logW[tb * N + n] - a.lse[tb]) * kLog2e);
+        const float dlw = (a.dlse ? a.dlse[tb] : 0.f) * sm + (a.dlogW_ext ? a.dlogW_ext[tb * N + n] : 0.f);
+        float kap[DX], ifs[DX];
 #pragma unroll
-    for (int k = 0; k < DX; ++k) {
-        float ek[DX], col[DX];
+        for (int d = 0; d < DX; ++d) {
+            const float i1 = 1.f / a.sig_q1[d];
+            kap[d] = a.two_q ? i1 / (i1 + 1.f / a.sig_q2[d]) : 1.f;     // c / s1
+            ifs[d] = i1;                                                // bootstrap: the transition scale is sigma_q1
+        }
+        __syncthreads();
+        float dxg[DX];
 #pragma unroll
-        for (int d = 0; d < DX; ++d) { ek[d] = (d == k) ? 1.f : 0.f; col[d] = 0.f; }
-        MQ::template bwd_input<kRolled>(wq1, x, ek, col);          // J^T e_k
+        for (int d = 0; d < DX; ++d) dxg[d] = 0.f;
+        {
+            float gm[DY], dgm[DY];
+            MG::template eval<kRolled>(wg, x, gm);
 #pragma unroll
-        for (int d = 0; d < DX; ++d) cf[d * DX + k] = kap[d] * col[d];
+            for (int k = 0; k < DY; ++k) {
+                float dmean = 1.f;
+                if (a.emission) { dmean = emis_dmean(gm[k]); gm[k] = emis_mean(gm[k]); }
+                const float isg = 1.f / a.sig_g[k];
+                dgm[k] = dlw * (y[k] - gm[k]) * isg * isg * dmean;
+            }
+            MG::template bwd_input<kRolled>(wg, x, dgm, dxg);
+        }
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            const float tf = dlw * (x[d] - fmean[d]) * ifs[d] * ifs[d];
+            rec[DX * DX + d] = fmaf(kap[d], dxg[d] - tf, tf);
+        }
+#pragma unroll
+        for (int k = 0; k < DX; ++k) {
+            float ek[DX], col[DX];
+#pragma unroll
+            for (int d = 0; d < DX; ++d) { ek[d] = (d == k) ? 1.f : 0.f; col[d] = 0.f; }
+            MQ::template bwd_input<kRolled>(wq1, x, ek, col);          // J^T e_k
+#pragma unroll
+            for (int d = 0; d < DX; ++d) rec[d * DX + k] = kap[d] * col[d];
+        }
     }
     if (valid) {
+        // float4 i of the record at [(tb R4 + i) N + n]: a wave's accesses are 16 bytes per lane AND contiguous over the lanes
+        // (particle-major records -- 112 bytes apart at Dx = 4 -- cost 64 cache lines per access: C5 67.0 -> 69.1 ms)
+        float4* dst = reinterpret_cast<float4*>(a.scanAB) + (tb * (SR::REC / 4)) * N + n;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) a.scanAB[(tb * NC + i) * N + n] = cf[i];
+        for (int i = 0; i < SR::REC / 4; ++i) dst[(size_t)i * N] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
     }
 }
 
@@ -940,34 +962,33 @@ __global__ void __launch_bounds__(512) fbs_coeff_kernel(const FilterBwdArgs a) {
 // per lane (N <= 64 NWV PPL), DEPTH steps of coefficients in flight: a step takes ~0.2 us and HBM ~2 us, so the loads of step
 // t - DEPTH are issued when step t is consumed (a ring of DEPTH register sets, the step loop unrolled DEPTH times so that every
 // index into it is static).
-template <int DX, int NWV, int PPL, int DEPTH>
+template <int DX, int NWV, int PPL, int DEPTH, int NCP = NWV>
 __global__ void __launch_bounds__(64 * NWV) fbs_scan_kernel(const FilterBwdArgs a) {
-    constexpr int NC = DX * DX + DX, NTS = 64 * NWV;
+    using SR = ScanRec<DX>;
+    constexpr int NTS = 64 * NWV, R4 = SR::REC / 4;
+    // NCP = NWV: one scatter copy per wave (fixed summation order; the launcher's choice at every N).  NCP = 1: one shared copy
+    // and LDS float atomics across the waves -- measured at C5 (N = 512, Dx = 4): 68.4 against 68.3 ms, the copies are not what
+    // the step waits for
     // scatter targets: one copy per wave, summed by the parent in wave order (LDS adds of ONE wave are applied in lane order,
     // adds of several waves in arrival order: with the copies every sum has a fixed order, as in filter_bwd_lpp_kernel)
     extern __shared__ __attribute__((aligned(16))) float acc[];      // [2][NWV][DX][N]
     const int tid = threadIdx.x, b = blockIdx.x, B = a.B, T = a.T, N = a.N;
-    const int CPY = DX * N, mine = (tid >> 6) * CPY;
-    for (int i = tid; i < 2 * NWV * CPY; i += NTS) acc[i] = 0.f;
-    float cf[DEPTH][PPL][NC], ext[DEPTH][PPL][DX];
-    int an[DEPTH][PPL];
-    auto load = [&](int t, float (&c)[PPL][NC], float (&e)[PPL][DX], int (&q)[PPL]) {
+    const int CPY = DX * N, mine = (NCP > 1 ? (tid >> 6) : 0) * CPY;
+    for (int i = tid; i < 2 * NCP * CPY; i += NTS) acc[i] = 0.f;
+    float4 rec[DEPTH][PPL][R4];
+    auto load = [&](int t, float4 (&r)[PPL][R4]) {
         const size_t tb = (size_t)t * B + b;
 #pragma unroll
         for (int p = 0; p < PPL; ++p) {
             const int n = min(tid + NTS * p, N - 1);
+            const float4* src = reinterpret_cast<const float4*>(a.scanAB) + (tb * R4) * N + n;
 #pragma unroll
-            for (int d = 0; d < DX; ++d) e[p][d] = a.dFm_ext ? a.dFm_ext[(tb * DX + d) * N + n] : 0.f;
-            if (t >= 1) {
-                q[p] = a.idx[(tb - B) * N + n];
-#pragma unroll
-                for (int i = 0; i < NC; ++i) c[p][i] = a.scanAB[(tb * NC + i) * N + n];
-            }
+            for (int i = 0; i < R4; ++i) r[p][i] = src[(size_t)i * N];
         }
     };
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s)
-        if (T - 1 - s >= 0) load(T - 1 - s, cf[s], ext[s], an[s]);
+        if (T - 1 - s >= 0) load(T - 1 - s, rec[s]);
     if (NWV > 1) __syncthreads();
     for (int t0 = T - 1; t0 >= 0; t0 -= DEPTH) {
 #pragma unroll
@@ -975,9 +996,19 @@ __global__ void __launch_bounds__(64 * NWV) fbs_scan_kernel(const FilterBwdArgs 
             const int t = t0 - s;
             if (t < 0) break;
             const size_t tb = (size_t)t * B + b;
-            float* cur = acc + (t & 1) * NWV * CPY;
-            float* nxt = acc + ((t + 1) & 1) * NWV * CPY + mine;
+            float* cur = acc + (t & 1) * NCP * CPY;
+            float* nxt = acc + ((t + 1) & 1) * NCP * CPY + mine;
             float D[PPL][DX];
+            float cf[PPL][SR::REC];
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+#pragma unroll
+                for (int i = 0; i < R4; ++i) {
+                    cf[p][4 * i] = rec[s][p][i].x; cf[p][4 * i + 1] = rec[s][p][i].y;
+                    cf[p][4 * i + 2] = rec[s][p][i].z; cf[p][4 * i + 3] = rec[s][p][i].w;
+                }
+            }
+            if (t - DEPTH >= 0) load(t - DEPTH, rec[s]);      // refill the slot just consumed
 #pragma unroll
             for (int p = 0; p < PPL; ++p) {
                 const int n = tid + NTS * p;
@@ -986,11 +1017,11 @@ __global__ void __launch_bounds__(64 * NWV) fbs_scan_kernel(const FilterBwdArgs 
                     for (int d = 0; d < DX; ++d) {
                         float v = 0.f;
 #pragma unroll
-                        for (int w = 0; w < NWV; ++w) {
+                        for (int w = 0; w < NCP; ++w) {
                             v += cur[w * CPY + d * N + n];
                             cur[w * CPY + d * N + n] = 0.f;
                         }
-                        D[p][d] = v + ext[s][p][d];
+                        D[p][d] = v + cf[p][SR::kExt + d];
                         a.dP[(tb * DX + d) * N + n] = D[p][d];
                     }
                 }
@@ -1000,19 +1031,21 @@ __global__ void __launch_bounds__(64 * NWV) fbs_scan_kernel(const FilterBwdArgs 
                 for (int p = 0; p < PPL; ++p) {
                     const int n = tid + NTS * p;
                     if (n < N) {
+                        const int an = __float_as_int(cf[p][SR::kAnc]);
 #pragma unroll
                         for (int d = 0; d < DX; ++d) {
-                            float v = cf[s][p][DX * DX + d];
+                            float v = cf[p][DX * DX + d];
 #pragma unroll
-                            for (int k = 0; k < DX; ++k) v = fmaf(cf[s][p][d * DX + k], D[p][k], v);
-                            atomicAdd(&nxt[d * N + an[s][p]], v);
+                            for (int k = 0; k < DX; ++k) v = fmaf(cf[p][d * DX + k], D[p][k], v);
+                            atomicAdd(&nxt[d * N + an], v);
                         }
                     }
                 }
             }
-            if (t - DEPTH >= 0) load(t - DEPTH, cf[s], ext[s], an[s]);      // refill the slot just consumed
             if (NWV > 1) {
-                __syncthreads();
+                // a workgroup barrier that orders the LDS traffic of the step ONLY: __syncthreads() also waits for every
+                // outstanding global access (s_waitcnt vmcnt(0)), i.e. for the record loads just issued for DEPTH steps ahead
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1173,10 +1206,9 @@ static void launch_filter_bwd_scan(const FilterBwdArgs& a, hipStream_t stream) {
     using AC = FAcc<DX, DY>;
     const int NT = (a.N + 63) & ~63;
     const size_t ldsw = sizeof(float) * (MQ::kSize + MG::kSize);
-    if (a.T >= 2)
-        hipLaunchKernelGGL((fbs_coeff_kernel<DX, DY, H>), dim3(a.T - 1, a.B), dim3(NT), ldsw, stream, a);
+    hipLaunchKernelGGL((fbs_coeff_kernel<DX, DY, H>), dim3(a.T, a.B), dim3(NT), ldsw, stream, a);
     const size_t ldss = sizeof(float) * 2 * DX * a.N * (a.N <= 128 ? 1 : 4);
-    // registers of the coefficient ring: DEPTH x PPL x (Dx^2 + 2 Dx + 1) -- <= ~300 of the 512 a lone wave per SIMD may use
+    // registers of the record ring: DEPTH x PPL x REC (12 / 16 / 28 floats) -- <= ~250 of the 512 a lone wave per SIMD may use
     constexpr int D1 = (DX == 2) ? 16 : (DX == 3) ? 12 : 8, D2 = D1 / 2;
     if (a.N <= 64) hipLaunchKernelGGL((fbs_scan_kernel<DX, 1, 1, D1>), dim3(a.B), dim3(64), ldss, stream, a);
     else if (a.N <= 128) hipLaunchKernelGGL((fbs_scan_kernel<DX, 1, 2, D2>), dim3(a.B), dim3(64), ldss, stream, a);
@@ -1269,9 +1301,9 @@ static int fb_dispatch_dy(const FilterBwdArgs& a, const FilterBwdOut& o, int Dy,
 extern "C" int psvo_filter_acc_size(int Dx, int Dy) { return 10 * Dx + Dy; }
 
 extern "C" long long psvo_filter_ws_floats(int B, int T, int N, int Dx, int Dy) {
-    // per-sequence sums | d mu2 rows | affine-scan coefficients (T,B,Dx*Dx+Dx,N) | per-step partial sums (T,B,NACC)
-    return (long long)B * (10 * Dx + Dy) + (long long)T * B * Dx * N + (long long)T * B * (Dx * Dx + Dx) * N +
-           (long long)T * B * (10 * Dx + Dy);
+    // per-sequence sums | d mu2 rows | affine-scan records (T,B,N,REC) | per-step partial sums (T,B,NACC)
+    const long long rec = (Dx * Dx + 2 * Dx + 1 + 3) / 4 * 4;      // ScanRec<Dx>::REC
+    return (long long)B * (10 * Dx + Dy) + (long long)T * B * Dx * N + 4 + (long long)T * B * rec * N + (long long)T * B * (10 * Dx + Dy);
 }
 #endif
 
@@ -1315,8 +1347,12 @@ PSVO_ENTRY(psvo_filter_backward)(
     a.dlse = dlse; a.nparts = nparts; a.dFm_ext = dFm_ext; a.dlogW_ext = dlogW_ext;
     a.dP = dP; a.dF = dF; a.dG = dG; a.dmu2 = dmu2; a.dm0 = dm0; a.dfm0 = dfm0; a.sacc = sacc;
     a.dm2_rows = sacc + (size_t)desc->B * psvo_filter_acc_size(desc->Dx, desc->Dy);
-    a.scanAB = a.dm2_rows + (size_t)desc->T * desc->B * desc->Dx * desc->N;
-    a.scanPart = a.scanAB + (size_t)desc->T * desc->B * (desc->Dx * desc->Dx + desc->Dx) * desc->N;
+    {   // the records are read with 16-byte accesses: their offset inside the (16-byte aligned) workspace is rounded up
+        const size_t off = (size_t)desc->B * psvo_filter_acc_size(desc->Dx, desc->Dy) + (size_t)desc->T * desc->B * desc->Dx * desc->N;
+        a.scanAB = sacc + ((off + 3) & ~(size_t)3);
+    }
+    if (reinterpret_cast<uintptr_t>(a.scanAB) & 15) a.scanAB = nullptr;      // (a misaligned workspace: the persistent kernel)
+    a.scanPart = a.scanAB + (size_t)desc->T * desc->B * ((desc->Dx * desc->Dx + 2 * desc->Dx + 1 + 3) / 4 * 4) * desc->N;
     FilterBwdOut o{dsig_q1, dsig_q2, dsig_f, dsig_g, dsig0, dfsig0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (desc->Dx) {
