@@ -294,6 +294,8 @@ struct BwdArgs {
     float* sacc;       // (B, 2 Dx + Dy): sums of d sigma over the rows of the q1 / f / g heads (= d sigma_con)
     float* dm2_rows;   // (T,B,Dx,N) per-particle d mu2, summed over N afterwards
     float* ds2_rows;   // (T,B,Dx,N) per-particle d sig2
+    float* scanRec;    // affine-scan path: float4 planes [(t, b), float4 index, particle] of the step records; scanPart (T,B,2Dx+Dy)
+    float* scanPart;
 };
 
 __device__ __forceinline__ float block_sum(float v, float* red, int wave, int lane, int nw) {
@@ -661,6 +663,402 @@ static int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The reverse pass as an AFFINE SCAN (filter_bwd.hip has the idea; bootstrap wiring with resampling).  Here a particle hands
+// D = (d mean, d scale) of its MLP_q1 evaluation -- 2 Dx values -- to its parent, and the parent's contribution is affine in it:
+//     [alpha dx + tf | beta dx + gamma + dfs],   dx = dx0 + J^T [d mean | hx d scale]   (J: the 2 Dx-output MLP's Jacobian)
+// with per-particle alpha = c / s1, beta = -(c mean1 - c^2 (eps + mu / c)) / s1^2, gamma = c^2 (dlw / c) / s1^2 from the product of
+// Gaussians on scales (not two_q: alpha = 1, beta = eps, gamma = dlw / c).  Record per (t, sequence, particle):
+//     [ M (2 Dx x 2 Dx) | b (2 Dx) | upstream d Fm, d Fs (2 Dx) | ancestor ]  as float4 planes.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int DX>
+struct CovRec {
+    static constexpr int D2 = 2 * DX;
+    static constexpr int kB = D2 * D2, kExt = kB + D2, kAnc = kExt + D2;
+    static constexpr int REC = (kAnc + 1 + 3) & ~3;
+};
+
+// forward quantities of one (t, particle) that both the coefficient and the rows kernel need
+template <int DX, int DY>
+struct CovStep {
+    float x[DX], e[DX], m2[DX], y[DY], mean1[DX], s1[DX], fmean[DX], fs[DX], own[DX];
+    float i1[DX], i2[DX], ic[DX], c[DX], mu[DX], dlw;
+    int anc;
+    __device__ __forceinline__ void load(const BwdArgs& a, int t, int b, int n, bool valid) {
+        const int B = a.B, N = a.N;
+        const size_t tb = (size_t)t * B + b;
+        const bool first = (t == 0);
+        anc = first ? n : a.idx[(tb - B) * N + n];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            x[d] = a.X[(tb * DX + d) * N + n];
+            e[d] = a.eps[(tb * DX + d) * N + n];
+            m2[d] = a.two_q ? a.mu2[tb * DX + d] : 0.f;
+            const float s2 = a.two_q ? a.sig2[tb * DX + d] : 1.f;
+            fmean[d] = first ? a.fm0[b * DX + d] : a.Fm[((tb - B) * DX + d) * N + anc];
+            fs[d] = first ? a.fsig0[b * DX + d] : a.Fs[((tb - B) * DX + d) * N + anc];
+            mean1[d] = first ? a.m0[b * DX + d] : fmean[d];
+            s1[d] = first ? a.sig0[b * DX + d] : fs[d];
+            own[d] = a.Fs[(tb * DX + d) * N + n];
+            if (a.two_q) {
+                i1[d] = rcp(s1[d]);
+                i2[d] = rcp(s2);
+                ic[d] = i1[d] + i2[d];
+                c[d] = rcp(ic[d]);
+                mu[d] = c[d] * fmaf(i1[d], mean1[d], i2[d] * m2[d]);
+            } else {
+                i1[d] = i2[d] = 0.f;
+                c[d] = s1[d];
+                ic[d] = rcp(c[d]);
+                mu[d] = mean1[d];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DY; ++k) y[k] = a.obs[tb * DY + k];
+        const float sm = valid ? exp2_fast((a.logW[tb * N + n] - a.lse[tb]) * kLog2e) : 0.f;
+        dlw = valid ? (a.dlse ? a.dlse[tb] : 0.f) * sm + (a.dlogW_ext ? a.dlogW_ext[tb * N + n] : 0.f) : 0.f;
+    }
+};
+
+template <int DX, int DY, int H>
+__global__ void __launch_bounds__(512) fcs_coeff_kernel(const BwdArgs a) {
+    using MQ = MlpLds<DX, H, 2 * DX, 1>;
+    using MG = MlpLds<DX, H, 2 * DY, 1>;
+    using CR = CovRec<DX>;
+    constexpr bool kRolled = true;
+    constexpr int D2 = 2 * DX;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int t = blockIdx.x, b = blockIdx.y, B = a.B, N = a.N;
+    const bool valid = tid < N;
+    const int n = valid ? tid : N - 1;
+    const size_t tb = (size_t)t * B + b;
+    float rec[CR::REC];
+#pragma unroll
+    for (int i = 0; i < CR::REC; ++i) rec[i] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        rec[CR::kExt + d] = a.dFm_ext ? a.dFm_ext[(tb * DX + d) * N + n] : 0.f;
+        rec[CR::kExt + DX + d] = a.dFs_ext ? a.dFs_ext[(tb * DX + d) * N + n] : 0.f;
+    }
+    if (t >= 1) {
+        float* wq1 = smem;
+        float* wg = wq1 + MQ::kSize;
+        MQ::load(wq1, a.q1, tid, NT);
+        MG::load(wg, a.g, tid, NT);
+        CovStep<DX, DY> s;
+        s.load(a, t, b, n, valid);
+        rec[CR::kAnc] = __int_as_float(s.anc);
+        __syncthreads();
+        float dx0[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) dx0[d] = 0.f;
+        {
+            float go[2 * DY], dgo[2 * DY];
+            MG::template eval<kRolled>(wg, s.x, go);
+#pragma unroll
+            for (int k = 0; k < DY; ++k) {
+                if (a.emission) {
+                    dgo[k] = s.dlw * (s.y[k] - emis_mean(go[k])) * emis_dmean(go[k]);
+                    dgo[DY + k] = 0.f;
+                } else {
+                    const float hx = 0.1f * exp2_fast(go[DY + k] * kLog2e);
+                    const float isg = rcp(a.sc_g[k] + (hx + 1e-7f));
+                    const float z = (s.y[k] - go[k]) * isg;
+                    dgo[k] = s.dlw * z * isg;
+                    dgo[DY + k] = s.dlw * (z * z - 1.f) * isg * hx;
+                }
+            }
+            MG::template bwd_input<kRolled>(wg, s.x, dgo, dx0);
+        }
+        float al[DX], be[DX];
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+            const float ifs = rcp(s.fs[d]);
+            const float z = (s.x[d] - s.fmean[d]) * ifs;
+            const float tf = s.dlw * z * ifs;
+            const float dfsc = s.dlw * (z * z - 1.f) * ifs;
+            const float dc0 = s.dlw * s.ic[d];
+            dx0[d] -= tf;
+            float ga;
+            if (a.two_q) {
+                const float q = s.i1[d] * s.i1[d];
+                al[d] = s.c[d] * s.i1[d];
+                be[d] = -q * (s.c[d] * s.mean1[d] - s.c[d] * s.c[d] * (s.e[d] + s.mu[d] * s.ic[d]));
+                ga = q * s.c[d] * s.c[d] * dc0;
+            } else {
+                al[d] = 1.f;
+                be[d] = s.e[d];
+                ga = dc0;
+            }
+            rec[CR::kB + d] = fmaf(al[d], dx0[d], tf);
+            rec[CR::kB + DX + d] = fmaf(be[d], dx0[d], ga + dfsc);
+        }
+#pragma unroll
+        for (int k = 0; k < D2; ++k) {
+            float ek[D2], col[DX];
+#pragma unroll
+            for (int j = 0; j < D2; ++j) ek[j] = 0.f;
+            ek[k] = (k < DX) ? 1.f : (s.own[k < DX ? 0 : k - DX] - a.sc_q1[k < DX ? 0 : k - DX] - 1e-7f);   // d sigma / d raw of the own head
+#pragma unroll
+            for (int d = 0; d < DX; ++d) col[d] = 0.f;
+            MQ::template bwd_input<kRolled>(wq1, s.x, ek, col);
+#pragma unroll
+            for (int d = 0; d < DX; ++d) {
+                rec[d * D2 + k] = al[d] * col[d];
+                rec[(DX + d) * D2 + k] = be[d] * col[d];
+            }
+        }
+    }
+    if (valid) {
+        float4* dst = reinterpret_cast<float4*>(a.scanRec) + (tb * (CR::REC / 4)) * N + n;
+#pragma unroll
+        for (int i = 0; i < CR::REC / 4; ++i) dst[(size_t)i * N] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+    }
+}
+
+// D <- ext + scatter(M D + b), one or four waves per sequence; writes d mean into dP and d SCALE into dPs (the rows kernel turns
+// the latter into the raw-head row).  Same structure as psvo::l1::fbs_scan_kernel.
+template <int DX, int NWV, int PPL, int DEPTH>
+__global__ void __launch_bounds__(64 * NWV) fcs_scan_kernel(const BwdArgs a) {
+    using CR = CovRec<DX>;
+    constexpr int NTS = 64 * NWV, R4 = CR::REC / 4, D2 = 2 * DX;
+    extern __shared__ __attribute__((aligned(16))) float acc[];      // [2][NWV][D2][N]
+    const int tid = threadIdx.x, b = blockIdx.x, B = a.B, T = a.T, N = a.N;
+    const int CPY = D2 * N, mine = (tid >> 6) * CPY;
+    for (int i = tid; i < 2 * NWV * CPY; i += NTS) acc[i] = 0.f;
+    float4 rec[DEPTH][PPL][R4];
+    auto load = [&](int t, float4 (&r)[PPL][R4]) {
+        const size_t tb = (size_t)t * B + b;
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) {
+            const int n = min(tid + NTS * p, N - 1);
+            const float4* src = reinterpret_cast<const float4*>(a.scanRec) + (tb * R4) * N + n;
+#pragma unroll
+            for (int i = 0; i < R4; ++i) r[p][i] = src[(size_t)i * N];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s)
+        if (T - 1 - s >= 0) load(T - 1 - s, rec[s]);
+    if (NWV > 1) __syncthreads();
+    for (int t0 = T - 1; t0 >= 0; t0 -= DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            const int t = t0 - s;
+            if (t < 0) break;
+            const size_t tb = (size_t)t * B + b;
+            float* cur = acc + (t & 1) * NWV * CPY;
+            float* nxt = acc + ((t + 1) & 1) * NWV * CPY + mine;
+            float cf[PPL][CR::REC], D[PPL][D2];
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+#pragma unroll
+                for (int i = 0; i < R4; ++i) {
+                    cf[p][4 * i] = rec[s][p][i].x; cf[p][4 * i + 1] = rec[s][p][i].y;
+                    cf[p][4 * i + 2] = rec[s][p][i].z; cf[p][4 * i + 3] = rec[s][p][i].w;
+                }
+            }
+            if (t - DEPTH >= 0) load(t - DEPTH, rec[s]);
+#pragma unroll
+            for (int p = 0; p < PPL; ++p) {
+                const int n = tid + NTS * p;
+                if (n < N) {
+#pragma unroll
+                    for (int d = 0; d < D2; ++d) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NWV; ++w) {
+                            v += cur[w * CPY + d * N + n];
+                            cur[w * CPY + d * N + n] = 0.f;
+                        }
+                        D[p][d] = v + cf[p][CR::kExt + d];
+                    }
+#pragma unroll
+                    for (int d = 0; d < DX; ++d) {
+                        a.dP[(tb * DX + d) * N + n] = D[p][d];
+                        a.dPs[(tb * DX + d) * N + n] = D[p][DX + d];
+                    }
+                }
+            }
+            if (t >= 1) {
+#pragma unroll
+                for (int p = 0; p < PPL; ++p) {
+                    const int n = tid + NTS * p;
+                    if (n < N) {
+                        const int an = __float_as_int(cf[p][CR::kAnc]);
+#pragma unroll
+                        for (int d = 0; d < D2; ++d) {
+                            float v = cf[p][CR::kB + d];
+#pragma unroll
+                            for (int k = 0; k < D2; ++k) v = fmaf(cf[p][d * D2 + k], D[p][k], v);
+                            atomicAdd(&nxt[d * N + an], v);
+                        }
+                    }
+                }
+            }
+            if (NWV > 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only: see fbs_scan_kernel)
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+}
+
+// everything else filter_cov_bwd_kernel produces, from D: one workgroup per (t, sequence)
+template <int DX, int DY, int H>
+__global__ void __launch_bounds__(512) fcs_rows_kernel(const BwdArgs a) {
+    using MQ = MlpLds<DX, H, 2 * DX, 1>;
+    using MG = MlpLds<DX, H, 2 * DY, 1>;
+    constexpr bool kRolled = true;
+    constexpr int NA = 2 * DX + DY;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x, nw = NT >> 6;
+    const int t = blockIdx.x, b = blockIdx.y, B = a.B, N = a.N;
+    const bool valid = tid < N, first = (t == 0);
+    const int n = valid ? tid : N - 1;
+    const size_t tb = (size_t)t * B + b;
+    float* wq1 = smem;
+    float* wg = wq1 + MQ::kSize;
+    float* red = wg + MG::kSize;      // [nw][NA + 4 DX]
+    MQ::load(wq1, a.q1, tid, NT);
+    MG::load(wg, a.g, tid, NT);
+    CovStep<DX, DY> s;
+    s.load(a, t, b, n, valid);
+    float dpm[DX], dps[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        dpm[d] = valid ? a.dP[(tb * DX + d) * N + n] : 0.f;
+        dps[d] = valid ? a.dPs[(tb * DX + d) * N + n] : 0.f;
+    }
+    __syncthreads();
+    float sums[NA + 4 * DX];      // d sigma sums of the q1 head (DX), [f head: unused, DX], g head (DY); t = 0: d m0, d sig0, d fm0, d fsig0
+#pragma unroll
+    for (int i = 0; i < NA + 4 * DX; ++i) sums[i] = 0.f;
+    float dx[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) dx[d] = 0.f;
+    {
+        float go[2 * DY], dgo[2 * DY];
+        MG::template eval<kRolled>(wg, s.x, go);
+#pragma unroll
+        for (int k = 0; k < DY; ++k) {
+            if (a.emission) {
+                dgo[k] = s.dlw * (s.y[k] - emis_mean(go[k])) * emis_dmean(go[k]);
+                dgo[DY + k] = 0.f;
+            } else {
+                const float hx = 0.1f * exp2_fast(go[DY + k] * kLog2e);
+                const float isg = rcp(a.sc_g[k] + (hx + 1e-7f));
+                const float z = (s.y[k] - go[k]) * isg;
+                dgo[k] = s.dlw * z * isg;
+                const float dsg = s.dlw * (z * z - 1.f) * isg;
+                dgo[DY + k] = dsg * hx;
+                sums[2 * DX + k] = dsg;
+            }
+            if (valid) {
+                a.dG[(tb * DY + k) * N + n] = dgo[k];
+                a.dGs[(tb * DY + k) * N + n] = dgo[DY + k];
+            }
+        }
+        MG::template bwd_input<kRolled>(wg, s.x, dgo, dx);
+    }
+    float dfmean[DX], dfsc[DX], dc[DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        const float ifs = rcp(s.fs[d]);
+        const float z = (s.x[d] - s.fmean[d]) * ifs;
+        const float tf = s.dlw * z * ifs;
+        dx[d] -= tf;
+        dfmean[d] = tf;
+        dfsc[d] = s.dlw * (z * z - 1.f) * ifs;
+        dc[d] = s.dlw * s.ic[d];
+    }
+    float dPo[2 * DX];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        sums[d] = dps[d];
+        dPo[d] = dpm[d];
+        dPo[DX + d] = dps[d] * (s.own[d] - a.sc_q1[d] - 1e-7f);
+        if (valid) a.dPs[(tb * DX + d) * N + n] = dPo[DX + d];       // (dP already holds d mean)
+    }
+    MQ::template bwd_input<kRolled>(wq1, s.x, dPo, dx);
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+        const float dmu = dx[d];
+        const float dct = fmaf(dmu, s.e[d], dc[d]);
+        float dmean1, ds1;
+        if (a.two_q) {
+            const float dA = dmu * s.c[d];
+            const float dic = -(dct + dmu * s.mu[d] * s.ic[d]) * s.c[d] * s.c[d];
+            const float di1 = fmaf(dA, s.mean1[d], dic), di2 = fmaf(dA, s.m2[d], dic);
+            dmean1 = dA * s.i1[d];
+            ds1 = -di1 * s.i1[d] * s.i1[d];
+            if (valid) {
+                a.dm2_rows[(tb * DX + d) * N + n] = dA * s.i2[d];
+                a.ds2_rows[(tb * DX + d) * N + n] = -di2 * s.i2[d] * s.i2[d];
+            }
+        } else {
+            dmean1 = dmu;
+            ds1 = dct;
+        }
+        if (first) {
+            sums[NA + d] = dmean1;
+            sums[NA + DX + d] = ds1;
+            sums[NA + 2 * DX + d] = dfmean[d];
+            sums[NA + 3 * DX + d] = dfsc[d];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NA + 4 * DX; ++i) {
+        const float v = wave_sum(valid ? sums[i] : 0.f);
+        if (lane == 0) red[wave * (NA + 4 * DX) + i] = v;
+    }
+    __syncthreads();
+    if (tid < NA + 4 * DX) {
+        float v = 0.f;
+        for (int w = 0; w < nw; ++w) v += red[w * (NA + 4 * DX) + tid];
+        if (tid < NA) a.scanPart[tb * NA + tid] = v;
+        else if (first) {
+            const int q = (tid - NA) / DX, d = (tid - NA) % DX;
+            float* dst = q == 0 ? a.dm0 : q == 1 ? a.dsig0 : q == 2 ? a.dfm0 : a.dfsig0;
+            dst[b * DX + d] = v;
+        }
+    }
+}
+
+// sacc[b][i] = sum_t part[t][b][i]: one wave per (b, i)
+__global__ void __launch_bounds__(256) fcs_fold_kernel(const float* __restrict__ part, int T, int B, int NA, float* __restrict__ sacc) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < NA; i += 4) {
+        float v = 0.f;
+        for (int t = lane; t < T; t += 64) v += part[((size_t)t * B + b) * NA + i];
+        v = wave_sum(v);
+        if (lane == 0) sacc[(size_t)b * NA + i] = v;
+    }
+}
+
+template <int DX, int DY, int H>
+static void launch_bwd_scan(const BwdArgs& a, hipStream_t stream) {
+    using MQ = MlpLds<DX, H, 2 * DX, 1>;
+    using MG = MlpLds<DX, H, 2 * DY, 1>;
+    const int NT = (a.N + 63) & ~63;
+    const size_t ldsw = sizeof(float) * (MQ::kSize + MG::kSize);
+    hipLaunchKernelGGL((fcs_coeff_kernel<DX, DY, H>), dim3(a.T, a.B), dim3(NT), ldsw, stream, a);
+    const size_t ldss = sizeof(float) * 2 * 2 * DX * a.N * (a.N <= 128 ? 1 : 4);
+    // record ring: DEPTH x PPL x REC (28 / 52 / 84 floats)
+    constexpr int D1 = (DX == 2) ? 8 : (DX == 3) ? 4 : 2, D2 = (DX == 2) ? 4 : (DX == 3) ? 2 : 1;
+    if (a.N <= 64) hipLaunchKernelGGL((fcs_scan_kernel<DX, 1, 1, D1>), dim3(a.B), dim3(64), ldss, stream, a);
+    else if (a.N <= 128) hipLaunchKernelGGL((fcs_scan_kernel<DX, 1, 2, D2>), dim3(a.B), dim3(64), ldss, stream, a);
+    else if (a.N <= 256) hipLaunchKernelGGL((fcs_scan_kernel<DX, 4, 1, D1>), dim3(a.B), dim3(256), ldss, stream, a);
+    else hipLaunchKernelGGL((fcs_scan_kernel<DX, 4, 2, D2>), dim3(a.B), dim3(256), ldss, stream, a);
+    const size_t ldsr = ldsw + sizeof(float) * ((NT / 64) * (2 * DX + DY + 4 * DX) + 16);
+    hipLaunchKernelGGL((fcs_rows_kernel<DX, DY, H>), dim3(a.T, a.B), dim3(NT), ldsr, stream, a);
+    hipLaunchKernelGGL(fcs_fold_kernel, dim3(a.B), dim3(256), 0, stream, a.scanPart, a.T, a.B, 2 * DX + DY, a.sacc);
+}
+
 struct BwdOut {
     float *dmu2, *dsig2, *dsc_q1, *dsc_f, *dsc_g;
 };
@@ -672,7 +1070,9 @@ static int launch_bwd(const BwdArgs& a, const BwdOut& o, hipStream_t stream) {
     const int NT = (a.N + 63) & ~63;
     const size_t lds = sizeof(float) * (2 * MQ::kSize + MG::kSize + (a.bootstrap ? 2 : 4) * (size_t)2 * DX * NT + 16);
     clear_hip_error();
-    if (NT <= 256) hipLaunchKernelGGL((filter_cov_bwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, a);
+    // the affine scan wherever it applies (this path is one stream: the reverse filter is always on its critical path)
+    if (g_tune_filter_bwd_scan && a.bootstrap && a.resample && a.scanRec && a.scanPart) launch_bwd_scan<DX, DY, H>(a, stream);
+    else if (NT <= 256) hipLaunchKernelGGL((filter_cov_bwd_kernel<DX, DY, H, 256>), dim3(a.B), dim3(NT), lds, stream, a);
     else hipLaunchKernelGGL((filter_cov_bwd_kernel<DX, DY, H, 512>), dim3(a.B), dim3(NT), lds, stream, a);
     if (a.two_q) {
         const long long rows = (long long)a.T * a.B * DX;
@@ -719,7 +1119,9 @@ static bool desc_ok(const psvo_desc* d) {
 }  // namespace psvo
 
 extern "C" long long psvo_filter_cov_ws_floats(int B, int T, int N, int Dx, int Dy) {
-    return (long long)B * (2 * Dx + Dy) + 2LL * T * B * Dx * N;
+    // per-sequence sums | d mu2 rows | d sig2 rows | (16-byte aligned) affine-scan records | per-step partial sums
+    const long long rec = (4 * Dx * Dx + 4 * Dx + 1 + 3) / 4 * 4;      // CovRec<Dx>::REC
+    return (long long)B * (2 * Dx + Dy) + 2LL * T * B * Dx * N + 4 + (long long)T * B * rec * N + (long long)T * B * (2 * Dx + Dy);
 }
 
 extern "C" int psvo_filter_forward_cov(const psvo_desc* desc, const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
@@ -783,6 +1185,12 @@ extern "C" int psvo_filter_backward_cov(
     a.sacc = ws;
     a.dm2_rows = ws + (size_t)desc->B * (2 * desc->Dx + desc->Dy);
     a.ds2_rows = a.dm2_rows + (size_t)desc->T * desc->B * desc->Dx * desc->N;
+    {
+        const size_t off = (size_t)desc->B * (2 * desc->Dx + desc->Dy) + 2 * (size_t)desc->T * desc->B * desc->Dx * desc->N;
+        a.scanRec = ws + ((off + 3) & ~(size_t)3);
+        a.scanPart = a.scanRec + (size_t)desc->T * desc->B * ((4 * desc->Dx * desc->Dx + 4 * desc->Dx + 1 + 3) / 4 * 4) * desc->N;
+        if (reinterpret_cast<uintptr_t>(a.scanRec) & 15) a.scanRec = nullptr;
+    }
     BwdOut o{dmu2, dsig2, dsigc_q1, dsigc_f, dsigc_g};
     hipStream_t s = static_cast<hipStream_t>(stream);
     PSVO_COV_DISPATCH(launch_bwd, a, o, s);
