@@ -190,7 +190,7 @@ int psvo_filter_forward_cov(const psvo_desc* desc,
  *            when bootstrap), dF / dFs for MLP_f (!bootstrap), dG / dGs (T,B,Dy,N) for MLP_g;
  *            dmu2, dsig2 (T,B,Dx); dm0, dsig0, dfm0, dfsig0 (B,Dx) (written separately even when the caller passed the
  *            same buffer as m0 and fm0: add them); dsigc_q1 / dsigc_f (Dx), dsigc_g (Dy) = d loss / d sigma_con.
- *  ws      : workspace, psvo_filter_cov_ws_floats(B, T, N, Dx, Dy) floats. */
+ *  ws      : workspace, psvo_filter_cov_ws_floats(B, T, N, Dx, Dy) floats, 16-byte aligned. */
 long long psvo_filter_cov_ws_floats(int B, int T, int N, int Dx, int Dy);
 int psvo_filter_backward_cov(const psvo_desc* desc,
                              const psvo_mlp* q1, const psvo_mlp* f, const psvo_mlp* g,
@@ -447,7 +447,9 @@ int psvo_bsimwr_backward(const psvo_desc* desc,
 /* ---------------------------------------------------------------------------------------------
  * Reverse mode of psvo_filter_forward.  The reference obtains these gradients from TensorFlow
  * autodiff of the tf.while_loop (reference src/trainer.py:115-118; no stop_gradient in src/,
- * SURVEY.md Appendix B).  One persistent workgroup per sequence walks t = T-1 .. 0.
+ * SURVEY.md Appendix B).  One persistent workgroup per sequence walks t = T-1 .. 0; in the bootstrap wiring with
+ * resampling (one hidden layer) the pass may instead run as an affine scan -- coefficients of every step in one parallel launch,
+ * one or four waves per sequence for the recurrence, rows and sums in a third launch (PSVO_TUNE_FILTER_BWD; same outputs).
  *
  *  inputs  : everything psvo_filter_forward took (eps as drawn), its outputs X, Fm, P1 (NULL when
  *            bootstrap), logW, lse, idx, and the upstream gradients
@@ -460,9 +462,9 @@ int psvo_bsimwr_backward(const psvo_desc* desc,
  *              dF (T,B,Dx,N) w.r.t. MLP_f(X_t) (only when !bootstrap), dG (T,B,Dy,N) w.r.t. MLP_g(X_t);
  *            hoisted-input gradients dmu2 (T,B,Dx), dm0 (B,Dx), dfm0 (B,Dx);
  *            scale gradients dsig_q1, dsig_q2, dsig_f, dsig0, dfsig0 (Dx), dsig_g (Dy).
- *  sacc    : workspace, psvo_filter_ws_floats(B, T, N, Dx, Dy) floats: B * psvo_filter_acc_size(Dx, Dy)
- *            per-sequence sums followed by the (T,B,Dx,N) per-particle rows of d mu2, which a parallel
- *            kernel sums over N after the time loop.
+ *  sacc    : workspace, psvo_filter_ws_floats(B, T, N, Dx, Dy) floats, 16-byte aligned: B * psvo_filter_acc_size(Dx, Dy)
+ *            per-sequence sums, the (T,B,Dx,N) per-particle rows of d mu2 (which a parallel kernel sums over N after the
+ *            time loop), the affine scan's step records and per-step partial sums.
  *  Aliasing rule: when fm0 and m0 are the SAME buffer (bootstrap and use_2_q: f_0 is q0's own density,
  *            SVO.py:86-92) d m0 receives the sum of both gradients and d fm0 is zero; likewise d sig0 / d fsig0 when
  *            fsig0 and sig0 are the same buffer.
