@@ -80,7 +80,8 @@ def test_invalid_arguments_are_rejected_without_a_device(built_lib):
                      "psvo_bsimwr_forward_cov", "psvo_bsimwr_backward_cov"):
             assert getattr(lib, name)(ctypes.byref(d), *nul_cov(name)) == want, (name, layers, emission)
     d.layers, d.emission = 1, 0
-    assert lib.psvo_filter_cov_ws_floats(2, 4, 8, 2, 1) == 2 * 5 + 2 * 4 * 2 * 2 * 8
+    # sums | two row sets | pad to 16 bytes | affine-scan records (4 Dx^2 + 4 Dx + 1 floats, rounded up to 4) | per-step partials
+    assert lib.psvo_filter_cov_ws_floats(2, 4, 8, 2, 1) == 2 * 5 + 2 * 4 * 2 * 2 * 8 + 4 + 4 * 2 * 28 * 8 + 4 * 2 * 5
     with pytest.raises(ValueError):
         _lib.check(_lib.PSVO_ERR_UNSUPPORTED, "x")
     with pytest.raises(_lib.PsvoHipError):
