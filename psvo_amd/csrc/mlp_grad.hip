@@ -14,6 +14,8 @@
 // (T,B,Dx,N) particle tensors have L = N, the bsim sub-particle tensors (T,B,Dx,N,M) have L = N*M.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace psvo {
 
 struct WgradArgs {
@@ -124,6 +126,186 @@ __global__ void __launch_bounds__(256) mlp_wgrad_kernel(const WgradArgs a, const
     }
 }
 
+// The default since round 3 (PSVO_WGRAD_OLD=1 selects the kernel above for A/B): the same arithmetic per (row, hidden unit),
+// restructured around what the kernel above loses.  At C* its two large launches (MLP_f and MLP_g of the backward simulation,
+// 1.3e7 rows each: 0.204 and 0.153 ms) are the tail of the step's critical path together with the encoder's reverse chain, at
+// 44 % of the vector-issue rate: per row and block column it spends ~270 instructions -- 205 arithmetic ones, a 64-bit
+// `r / L`, 16 v_readlane + s_nop for weights that hipcc keeps in spilled SGPRs -- waits for the row's four loads before the
+// first of them, and every block column (H / 16 of them) reads all rows again (2 x 210 MB at C*).
+//   * the four waves of a workgroup are (row group) x (block column): the columns of a workgroup read the SAME 64 rows
+//     (one trip to HBM, the other waves hit the cache of the same CU), and each wave keeps only its column's accumulators;
+//   * KC = 8 hidden units per column when Din + Dout > 4, so weights (<= 64 SGPRs) and accumulators (<= 73 VGPRs) fit
+//     four waves per SIMD in every instantiation (the kernel above: 16 units whatever the size);
+//   * (segment, row) advance incrementally with the grid stride -- no division in the loop -- and the next row's values are
+//     requested before the current row's arithmetic.
+// (Packed f32 pairs were measured first -- v_pk_fma_f32 over two hidden units, 15 instead of 24 instructions per unit
+// pair: 0.219 ms against 0.204 at C*.  On gfx950 a wave64 v_fma_f32 issues in two cycles, v_pk_fma_f32 in four: the same
+// 64 flop / clk / SIMD, twice the registers.)
+template <int DIN, int DOUT>
+struct WgradCols {
+    static constexpr int KC = (DIN + DOUT <= 4) ? 16 : 8;
+};
+
+template <int DIN, int DOUT>
+__global__ void __launch_bounds__(256) mlp_wgrad_cols_kernel(const WgradArgs a, const int H, const int cw_shift) {
+    constexpr int KC = WgradCols<DIN, DOUT>::KC;
+    constexpr int NPC = (DIN + 1 + DOUT) * KC + DOUT;  // per-column partial sums (+ db2, kept from column 0)
+    __shared__ float red[4][NPC];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int CW = 1 << cw_shift, RW = 4 >> cw_shift;      // columns / row groups of a workgroup: wave = rg * CW + c
+    const int c = wave & (CW - 1), rg = wave >> cw_shift;
+    const int k0 = (blockIdx.y * CW + c) * KC;
+
+    float w1[DIN][KC], b1[KC], w2[DOUT][KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        b1[k] = a.w.b1[k0 + k];
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) w1[i][k] = a.w.W1[i * H + k0 + k];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) w2[o][k] = a.w.W2[(k0 + k) * DOUT + o];
+    }
+    // w1, w2 stay in scalar registers (<= 64); pre = fma(x, w1, b1) may read ONE of them, so b1 lives in vector registers.
+    // (After all the loads: hipcc turns every uniform load that FOLLOWS an asm volatile into a per-lane global_load.)
+#pragma unroll
+    for (int k = 0; k < KC; ++k) keep_in_vgpr(b1[k]);
+
+    float gW1[DIN][KC], gb1[KC], gW2[DOUT][KC], gb2[DOUT];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        gb1[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) gW1[i][k] = 0.f;
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) gW2[o][k] = 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) gb2[o] = 0.f;
+
+    const int L = a.L;
+    const long long R = a.S * L;
+    const long long stride = (long long)gridDim.x * RW * 64;
+    const long long ds = stride / L;
+    const int dl = (int)(stride - ds * L);
+    const long long stepX = ds * DIN * L + dl, stepD = ds * DOUT * L + dl;
+    long long r = ((long long)blockIdx.x * RW + rg) * 64 + lane;
+    const long long s0 = r / L;
+    int l = (int)(r - s0 * L);
+    long long offX = s0 * DIN * L + l, offD = s0 * DOUT * L + l;
+
+    float xn[DIN], dn[DOUT];
+    auto request = [&]() {
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) xn[i] = a.X[offX + (long long)i * L];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) dn[o] = a.dOut[offD + (long long)o * L];
+    };
+    if (r < R) request();
+    while (r < R) {
+        float x[DIN], dout[DOUT];
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) x[i] = xn[i];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) {
+            dout[o] = dn[o];
+            gb2[o] += dout[o];
+        }
+        r += stride;
+        l += dl;
+        offX += stepX;
+        offD += stepD;
+        if (l >= L) {          // the stride crossed one more segment boundary
+            l -= L;
+            offX += (long long)(DIN - 1) * L;
+            offD += (long long)(DOUT - 1) * L;
+        }
+        if (r < R) request();
+
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            float pre = b1[k];
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) pre = fmaf(x[i], w1[i][k], pre);
+            const float h = fmaxf(pre, 0.f);
+            float dh = 0.f;
+#pragma unroll
+            for (int o = 0; o < DOUT; ++o) {
+                dh = fmaf(dout[o], w2[o][k], dh);
+                gW2[o][k] = fmaf(h, dout[o], gW2[o][k]);
+            }
+            dh = pre > 0.f ? dh : 0.f;
+            gb1[k] += dh;
+#pragma unroll
+            for (int i = 0; i < DIN; ++i) gW1[i][k] = fmaf(x[i], dh, gW1[i][k]);
+        }
+    }
+
+    // per-wave sums (the steps of wave_sum, each applied to ALL sums before the next: one value at a time every step waits
+    // out the DPP hazard of the one before -- 510 s_nop in 1 900 instructions, a third of the launch at the filter's 8e5
+    // rows), then the row groups of each column in fixed order
+    float acc[NPC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) acc[i * KC + k] = gW1[i][k];
+        acc[DIN * KC + k] = gb1[k];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) acc[(DIN + 1 + o) * KC + k] = gW2[o][k];
+    }
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) acc[(DIN + 1 + DOUT) * KC + o] = gb2[o];
+    // (eight sums at a time: enough distance for the hazard, and the steps' temporaries stay within eight registers --
+    // all NPC at once cost 46 more VGPRs and the fourth wave per SIMD)
+#pragma unroll
+    for (int p0 = 0; p0 < NPC; p0 += 8) {
+        constexpr int kStep = 8;
+#pragma unroll
+        for (int p = p0; p < p0 + kStep && p < NPC; ++p) acc[p] += dpp_mov<0x111, 0xF, 0xF, true>(0.f, acc[p]);      // row_shr:1
+#pragma unroll
+        for (int p = p0; p < p0 + kStep && p < NPC; ++p) acc[p] += dpp_mov<0x112, 0xF, 0xF, true>(0.f, acc[p]);      // row_shr:2
+#pragma unroll
+        for (int p = p0; p < p0 + kStep && p < NPC; ++p) acc[p] += dpp_mov<0x114, 0xF, 0xF, true>(0.f, acc[p]);      // row_shr:4
+#pragma unroll
+        for (int p = p0; p < p0 + kStep && p < NPC; ++p) acc[p] += dpp_mov<0x118, 0xF, 0xF, true>(0.f, acc[p]);      // row_shr:8
+#pragma unroll
+        for (int p = p0; p < p0 + kStep && p < NPC; ++p) acc[p] += dpp_mov<0x142, 0xA, 0xF, false>(0.f, acc[p]);     // row_bcast:15
+#pragma unroll
+        for (int p = p0; p < p0 + kStep && p < NPC; ++p) acc[p] += dpp_mov<0x143, 0xC, 0xF, false>(0.f, acc[p]);     // row_bcast:31
+#pragma unroll
+        for (int p = p0; p < p0 + kStep && p < NPC; ++p) asm volatile("" : "+v"(acc[p]));     // (groups stay apart)
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int p = 0; p < NPC; ++p) red[wave][p] = acc[p];
+    }
+    __syncthreads();
+    // scatter into the flat keras-layout vector dW1 (DIN,H) | db1 (H) | dW2 (H,DOUT) | db2 (DOUT)
+    const int NP = DIN * H + H + H * DOUT + DOUT;
+    float* dst = a.partial + (size_t)blockIdx.x * NP;
+    for (int q = tid; q < CW * NPC; q += 256) {
+        const int cc = q / NPC, p = q - cc * NPC;
+        float v = red[cc][p];
+        for (int g = 1; g < RW; ++g) v += red[g * CW + cc][p];
+        const int kc0 = (blockIdx.y * CW + cc) * KC;
+        if (p < (DIN + 1 + DOUT) * KC) {
+            const int row = p / KC, k = p - row * KC;
+            if (row < DIN) dst[row * H + kc0 + k] = v;
+            else if (row == DIN) dst[DIN * H + kc0 + k] = v;
+            else dst[DIN * H + H + (kc0 + k) * DOUT + (row - DIN - 1)] = v;
+        } else if (kc0 == 0) {
+            dst[DIN * H + H + H * DOUT + (p - (DIN + 1 + DOUT) * KC)] = v;
+        }
+    }
+}
+
+static bool wgrad_old_kernel() {
+    const char* e = getenv("PSVO_WGRAD_OLD");
+    return e && e[0] == '1';
+}
+
+
 // out[p] (+)= sum_blk partial[blk][p]: one wave per output element, lanes stride over the blocks
 // (fixed order, deterministic)
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int NP, float* __restrict__ out,
@@ -139,7 +321,13 @@ template <int DIN, int DOUT>
 static int launch_wgrad(const WgradArgs& a, int H, int nblk, float* out, int accumulate, hipStream_t s) {
     const int NP = DIN * H + H + H * DOUT + DOUT;
     clear_hip_error();
-    hipLaunchKernelGGL((mlp_wgrad_kernel<DIN, DOUT>), dim3(nblk, H / kKC), dim3(256), 0, s, a, H);
+    if (wgrad_old_kernel()) {
+        hipLaunchKernelGGL((mlp_wgrad_kernel<DIN, DOUT>), dim3(nblk, H / kKC), dim3(256), 0, s, a, H);
+    } else {
+        const int ncol = H / WgradCols<DIN, DOUT>::KC;
+        const int sh = ncol % 4 == 0 ? 2 : ncol % 2 == 0 ? 1 : 0;
+        hipLaunchKernelGGL((mlp_wgrad_cols_kernel<DIN, DOUT>), dim3(nblk, ncol >> sh), dim3(256), 0, s, a, H, sh);
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(NP), dim3(64), 0, s, a.partial, nblk, NP, out, accumulate);
     return launch_status();
 }

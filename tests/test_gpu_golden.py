@@ -272,6 +272,58 @@ def test_mlp2_wgrad_matches_torch(built_lib, shape, Din, H, Dout, wgrad2_variant
     assert [tuple(v.shape) for v in g4] == [(Din, H), (H,), (H, Dout), (Dout,), (H, H), (H,)]
 
 
+@pytest.mark.parametrize("shape", [(3, 2, 0, 50, 4), (1, 1, 0, 5), (2, 1, 0, 5000), (40, 8, 0, 100, 16), (200, 8, 0, 128, 16), (7, 3, 0, 130)])
+@pytest.mark.parametrize("H", [16, 32, 64])
+def test_mlp_wgrad_kernels(built_lib, monkeypatch, shape, H):
+    """psvo_mlp_wgrad (one hidden layer), every Din x Dout instantiation of the default kernel (the waves of a workgroup
+    are row groups x block columns over shared rows, 16 or 8 hidden units per column) against (a) torch autograd of the same
+    MLP in fp64 over the same rows, rel 1e-4 of a tensor's largest entry, and (b) the round-1 kernel (PSVO_WGRAD_OLD=1), which
+    sums the same products in another order: rel 2e-5.
+    Shapes: fewer rows than one workgroup, a segment longer than the grid stride, strides that are not a multiple of the
+    segment length (the incremental (segment, row) advance), and 3.3e6 rows on the full 1024-workgroup grid; H = 16 / 32 /
+    64 give 1 -- 8 block columns (1, 2 or 4 per workgroup)."""
+    from psvo_amd import ops
+    big = shape[0] * shape[1] * (shape[3] * (shape[4] if len(shape) > 4 else 1)) > 1_000_000
+    for Din in (1, 2, 3, 4):
+        for Dout in (1, 2, 3, 4):
+            if big and (Din, Dout) not in ((2, 2), (2, 1), (4, 4), (3, 1)):
+                continue
+            g = torch.Generator().manual_seed(sum(shape) + H + 10 * Din + Dout)
+            X = torch.randn(*(shape[:2] + (Din,) + shape[3:]), generator=g)
+            dOut = torch.randn(*(shape[:2] + (Dout,) + shape[3:]), generator=g)
+            W1 = torch.randn(Din, H, generator=g) / Din ** 0.5
+            b1 = 0.3 * torch.randn(H, generator=g)
+            W2 = torch.randn(H, Dout, generator=g) / H ** 0.5
+            b2 = 0.3 * torch.randn(Dout, generator=g)
+            w = tuple(t.cuda() for t in (W1, b1, W2, b2))
+            Xc, dc = X.cuda(), dOut.cuda()
+            monkeypatch.setenv("PSVO_WGRAD_OLD", "1")
+            old = ops.mlp_wgrad(Xc, dc, w, Din, H, Dout).clone()
+            monkeypatch.delenv("PSVO_WGRAD_OLD")
+            got = ops.mlp_wgrad(Xc, dc, w, Din, H, Dout)
+            torch.cuda.synchronize()
+            assert torch.allclose(got, old, atol=2e-5 * float(old.abs().max()) + 1e-6, rtol=2e-5), (Din, Dout)
+            ps = [t.double().cuda().requires_grad_(True) for t in (W1, b1, W2, b2)]
+            rows = Xc.double().movedim(2, -1).reshape(-1, Din)
+            # the relu mask as the kernel's f32 fma chain sees it (the exact product and sum in fp64, rounded once to f32):
+            # among 5e7 (row, unit) pairs a handful have a pre-activation whose sign differs between f32 and fp64, and one
+            # such row moves a sum by more than the bar
+            pre = b1.cuda()[None, :].expand(rows.shape[0], H)
+            for i in range(Din):
+                pre = (rows[:, i:i + 1] * ps[0][i].detach()[None, :] + pre.double()).float()
+            out = ((rows @ ps[0] + ps[1]) * (pre > 0)) @ ps[2] + ps[3]
+            out.backward(dc.double().movedim(2, -1).reshape(-1, Dout))
+            off = 0
+            for name, t in zip(("dW1", "db1", "dW2", "db2"), ps):
+                a, b = got[off:off + t.numel()].double(), t.grad.reshape(-1)
+                assert torch.allclose(a, b, atol=1e-4 * float(b.abs().max()) + 1e-6, rtol=1e-4), (name, Din, Dout)
+                off += t.numel()
+            acc = torch.ones_like(got)
+            ops.mlp_wgrad(Xc, dc, w, Din, H, Dout, grad=acc)
+            torch.cuda.synchronize()
+            assert torch.allclose(acc, got + 1.0, atol=1e-5 * float(got.abs().max()) + 1e-6, rtol=1e-5)
+
+
 @pytest.mark.parametrize("R,Din,H,Dout", [(6400, 64, 32, 2), (32, 1, 32, 2), (77, 128, 64, 4), (1000, 3, 16, 1)])
 def test_rows_mlp_matches_torch(built_lib, R, Din, H, Dout):
     """psvo_rows_mlp_forward / _backward (the hoisted q0 / q2 / BSim_q2 / BSim_q_init means) against the same MLP
