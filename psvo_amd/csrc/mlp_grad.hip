@@ -138,9 +138,12 @@ __global__ void __launch_bounds__(256) mlp_wgrad_kernel(const WgradArgs a, const
 //     four waves per SIMD in every instantiation (the kernel above: 16 units whatever the size);
 //   * (segment, row) advance incrementally with the grid stride -- no division in the loop -- and the next row's values are
 //     requested before the current row's arithmetic.
-// (Packed f32 pairs were measured first -- v_pk_fma_f32 over two hidden units, 15 instead of 24 instructions per unit
-// pair: 0.219 ms against 0.204 at C*.  On gfx950 a wave64 v_fma_f32 issues in two cycles, v_pk_fma_f32 in four: the same
-// 64 flop / clk / SIMD, twice the registers.)
+// Counters of the result (profiles/r03_sq_counters_mlp_wgrad.json): the four waves of a SIMD are each 51 % of their cycles
+// in a vector instruction (the kernel above: 34 %), 6 % parked on a load (21 %) -- the vector ALU is saturated and what is
+// left is instruction count: 215 per 64 rows x 16 units, 128 of them the FMAs of the algorithm.
+// (Packed f32 pairs -- v_pk_fma_f32 over two hidden units, weights and accumulators in register pairs -- were measured on
+// the old structure first: 0.219 ms against 0.204 at C*; that build carried 34 canonicalising v_max and 24 s_nop per row
+// and 192 VGPRs, two waves per SIMD.  Not repeated on this structure.)
 template <int DIN, int DOUT>
 struct WgradCols {
     static constexpr int KC = (DIN + DOUT <= 4) ? 16 : 8;
