@@ -139,11 +139,13 @@ __global__ void __launch_bounds__(256) mlp_wgrad_kernel(const WgradArgs a, const
 //   * (segment, row) advance incrementally with the grid stride -- no division in the loop -- and the next row's values are
 //     requested before the current row's arithmetic.
 // Counters of the result (profiles/r03_sq_counters_mlp_wgrad.json): the four waves of a SIMD are each 51 % of their cycles
-// in a vector instruction (the kernel above: 34 %), 6 % parked on a load (21 %) -- the vector ALU is saturated and what is
-// left is instruction count: 215 per 64 rows x 16 units, 128 of them the FMAs of the algorithm.
+// in a vector instruction (the kernel above: 34 %), 6 % parked on a load (21 %).  215 vector instructions per 64 rows x 16
+// units, 128 of them the FMAs of the algorithm, at 1.62 ns per instruction and SIMD; a stream of nothing but independent
+// v_fma_f32 runs at 1.22 ns at four waves per SIMD (tools/micro/valu_rate.hip, profiles/r03_valu_rate.txt: 107 TFLOP/s).
 // (Packed f32 pairs -- v_pk_fma_f32 over two hidden units, weights and accumulators in register pairs -- were measured on
 // the old structure first: 0.219 ms against 0.204 at C*; that build carried 34 canonicalising v_max and 24 s_nop per row
-// and 192 VGPRs, two waves per SIMD.  Not repeated on this structure.)
+// and 192 VGPRs, two waves per SIMD.  The same micro-benchmark: at four waves per SIMD a packed stream sustains 111 TFLOP/s
+// against 107 scalar -- the halved instruction count buys nothing once four waves share the SIMD; not repeated here.)
 template <int DIN, int DOUT>
 struct WgradCols {
     static constexpr int KC = (DIN + DOUT <= 4) ? 16 : 8;
