@@ -546,7 +546,9 @@ def main():
                                  "f32-input MFMA peak AND the packed f32 vector peak (`bound` keeps the contract's label for "
                                  "the compute roofline; `pipe` says which pipe executes it: the dominant kernel's default "
                                  "build issues its flops on the vector ALU -- the f32 MFMA variants were measured beside it "
-                                 "and do not co-execute with the VALU, profiles/r02_bsim_bwd_ab.md; it moves ~0.5 TB/s)"},
+                                 "and do not co-execute with the VALU, profiles/r02_bsim_bwd_ab.md; it moves ~0.5 TB/s; a stream of "
+                                 "nothing but independent f32 FMAs sustains 95 (scalar) -- 112 (packed) TFLOP/s at the two waves "
+                                 "per SIMD these kernels run: tools/micro/valu_rate.hip, profiles/r03_valu_rate.txt)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, P_ref, obs.cpu(), min(args.cpu_sample_T, T),
